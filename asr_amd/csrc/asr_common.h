@@ -1,0 +1,115 @@
+// Internal declarations shared by the HIP translation units of libasr_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ASR_D_HEAD 64          // hidden_units / num_heads of every reference config
+#define ASR_MAX_BEAM 32
+#define ASR_MAX_SPLITK 16
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- GEMM (gemm_f32.hip) -------------------------------------------------------------------
+enum GemmEpilogue {
+    EPI_BIAS = 0,      // C = acc + bias (bias may be null)
+    EPI_GLU = 1,       // W rows interleaved in groups of 32 (value | gate); C[m, n/2] = (a+b1)*sigmoid(g+b2)
+    EPI_PARTIAL = 2,   // C[z][m][n] = acc of K-slice z (split-K slabs, reduced by the consumer)
+    EPI_RELU = 3, EPI_SIGMOID = 4, EPI_TANH = 5, EPI_SWISH = 6   // 1-argument ff activations
+};
+
+struct GemmArgs {
+    const float* A;    // [M, K] row-major, leading dimension lda
+    const float* W;    // [N, K] row-major ("kernel [out, in]", utils.py:551), leading dimension ldw
+    const float* bias; // [N] or null
+    float* C;          // [M, ldc] (EPI_PARTIAL: [split_k][M][ldc])
+    int M, N, K;
+    int lda, ldw, ldc;
+    int split_k;       // >= 1; > 1 only with EPI_PARTIAL
+    int epilogue;
+};
+// tile_hint: 0 = choose from the shape, 1 = 128x128, 2 = 64x64, 3 = 64x128(M x N), 4 = 128x64
+hipError_t launch_gemm_f32(const GemmArgs& a, int tile_hint, hipStream_t s);
+// number of K-slices the decode-time projections should use for this shape (fills the chip)
+int gemm_pick_split_k(int M, int N, int K);
+
+// ---- row kernels (rowops.hip) ----------------------------------------------------------------
+hipError_t launch_frame_stack_lens(const float* raw, const int32_t* lens, int n, int raw_frames, int raw_dim, int left,
+                                   int right, int sub, float* out, hipStream_t s);
+hipError_t launch_frame_stack(const float* raw, int n, int raw_frames, int raw_dim, int left, int right,
+                              int sub, float* out, hipStream_t s);
+hipError_t launch_pad_mask(const float* X, int rows, int d, int32_t* pad, hipStream_t s);
+// contrib layer_norm over (t, hidden) per utterance + timing signal; scratch >= n*(2*chunks+2) doubles
+hipError_t launch_input_norm_timing(const float* x, const float* gamma, const float* beta, const float* pe,
+                                    int n, int t, int hidden, double* scratch, float* y, hipStream_t s);
+size_t input_norm_scratch_doubles(int n, int t, int hidden);
+// y = LN(resid + dbias + sum_z part[z]) * scale + bias; rows with mask[row] != 0 are zeroed;
+// pad2_out (optional) receives (sum |y| == 0)
+hipError_t launch_add_layer_norm(const float* resid, const float* part, int nsplit, size_t split_stride,
+                                 const float* dbias, const float* scale, const float* bias,
+                                 const int32_t* mask, int32_t* pad2_out, int rows, int hidden, float* y,
+                                 hipStream_t s);
+hipError_t launch_add_layer_norm_done(const float* resid, const float* part, int nsplit, size_t split_stride,
+                                      const float* dbias, const float* scale, const float* bias,
+                                      const int32_t* mask, int32_t* pad2_out, int rows, int hidden, float* y,
+                                      const int32_t* done, hipStream_t s);
+hipError_t launch_embed_pe(const float* E, const int32_t* preds0, const int32_t* preds1, int preds_stride,
+                           const int32_t* pos_dev, const float* pe, float mult, int rows, int hidden, float* y,
+                           const int32_t* done, hipStream_t s);
+// kv [n*t, 2*hidden] (k | v) -> kT [n][heads][64][tp], v [n][heads][t][64]
+hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int tp, int heads, float* kT, float* v,
+                                hipStream_t s);
+hipError_t launch_log_softmax_topk(const float* logits, int rows, int vocab, int k, float* values,
+                                   int32_t* indices, const int32_t* done, hipStream_t s);
+
+struct BeamState {       // device pointers; double-buffered arrays are indexed by (*pos & 1)
+    float* scores[2];          // [R]
+    int32_t* finished[2];      // [R]
+    int32_t* preds[2];         // [R, width]
+    int32_t* anc[2];           // [R, width] slot (0..K-1) holding position j of row r's history
+    int32_t* pos;              // [1] decode steps done so far (= position of the token fed next)
+    int32_t* done;             // [1] loop has ended
+    int32_t* unfinished;       // [1] scratch counter
+    int32_t* tokens;           // [R] last tokens (trace)
+    int32_t* parents;          // [R] last parents, global row index (trace)
+    int width;                 // max_target_length + 2
+    int limit;                 // min(T + 50, max_target_length)
+};
+hipError_t launch_beam_init(const BeamState& st, int b, int k, hipStream_t s);
+hipError_t launch_beam_step(const BeamState& st, const float* cand_scores, const int32_t* cand_tokens,
+                            int b, int k, hipStream_t s);
+// stand-alone pruning step for asr_op_beam_step
+hipError_t launch_beam_prune(const float* scores, const int32_t* finished, const float* cand_scores,
+                             const int32_t* cand_tokens, int b, int k, float* new_scores, int32_t* tokens,
+                             int32_t* parents, int32_t* finished_out, hipStream_t s);
+
+// ---- attention (attention.hip) ---------------------------------------------------------------
+hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads,
+                                    float* ctx, hipStream_t s);
+struct SelfAttnArgs {
+    const float* qkv;      // [nsplit][R][3*hidden] partial qkv projections (q | k | v), bias not yet added
+    int nsplit; size_t split_stride;
+    const float* bias;     // [3*hidden]
+    float* kcache;         // [b][width][K][hidden] for this block: position-major, beam slot inside
+    float* vcache;
+    const int32_t* anc0;   // BeamState.anc[0], anc[1]
+    const int32_t* anc1;
+    const int32_t* pos;
+    const int32_t* done;
+    float* ctx;            // [R, hidden]
+    int b, k, heads, width;
+};
+hipError_t launch_decoder_self_attention(const SelfAttnArgs& a, hipStream_t s);
+struct CrossAttnArgs {
+    const float* qpart;    // [nsplit][R][hidden] partial q projections
+    int nsplit; size_t split_stride;
+    const float* qbias;    // [hidden]
+    const float* kT;       // [b][heads][64][tp]
+    const float* v;        // [b][heads][t][64]
+    const int32_t* pad2;   // [b][t]
+    const int32_t* done;
+    float* ctx;            // [R, hidden]
+    int b, k, heads, t, tp;
+};
+hipError_t launch_decoder_cross_attention(const CrossAttnArgs& a, hipStream_t s);
+size_t cross_attention_lds_bytes(int k, int tp);

@@ -1,0 +1,381 @@
+// Attention kernels of the inference path (d_head = 64, fp32):
+//   * encoder self-attention: flash-style, exact-f32 MFMA, key-padding mask, K/V tiles staged in LDS
+//   * decoder self-attention: one query per row against the per-beam K/V cache in HBM
+//     (ancestry-table indirection instead of copying the cache on every beam reorder)
+//   * decoder cross-attention: the K beams of an utterance share one pass over that utterance's K/V
+// Replaces utils.multihead_attention's core (transformer/utils.py:621-631) and
+// common_attention.dot_product_attention (third_party/tensor2tensor/common_attention.py:295-334).
+#include "asr_common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder self-attention.  grid (ceil(t/128), heads, n), 4 waves x 32 query rows.
+// S^T = K.Q^T is computed (keys on the MFMA row index, queries on the lane), so each lane owns one
+// query: row max / sum are in-lane over 16 registers plus one exchange with lane^32, and the S^T
+// accumulator is already the B operand of O^T += V^T.P^T (no LDS round trip for P).
+// Mask: -1e9 added to logits of padded keys (common_attention.py:202), exactly as the reference;
+// keys beyond t (tile padding only) are excluded with -inf.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ pad,
+                                                                 int t, int heads, float* __restrict__ ctx)
+{
+    __shared__ f32x4 Ks[32 * 16];        // [key][16-B chunk ^ (key & 15)]
+    __shared__ float Vs[32 * 64];        // [key][d]
+    __shared__ float Bias[32];
+    __shared__ float Os[4][32][65];
+
+    const int qt = blockIdx.x, h = blockIdx.y, u = blockIdx.z;
+    const int hidden = heads * 64, ld = 3 * hidden;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int q0w = qt * 128 + wave * 32;
+    const int q = q0w + l31;
+    const float* base = qkv + (size_t)u * t * ld;
+
+    f32x4 qf[8];
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q < t) v = *reinterpret_cast<const f32x4*>(base + (size_t)q * ld + h * 64 + (2 * qq + half) * 4);
+        qf[qq] = v * 0.125f;                                   // q *= key_depth_per_head ** -0.5 (utils.py:628)
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (t + 31) / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 4, c = idx & 15;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + row < t) {
+                const float* rp = base + (size_t)(k0 + row) * ld + h * 64 + c * 4;
+                kv = *reinterpret_cast<const f32x4*>(rp + hidden);
+                vv = *reinterpret_cast<const f32x4*>(rp + 2 * hidden);
+            }
+            Ks[row * 16 + (c ^ (row & 15))] = kv;
+            reinterpret_cast<f32x4*>(Vs)[row * 16 + c] = vv;
+        }
+        if (tid < 32) {
+            const int kk = k0 + tid;
+            Bias[tid] = (kk >= t) ? -INFINITY : (pad[(size_t)u * t + kk] ? -1e9f : 0.0f);
+        }
+        __syncthreads();
+
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            const f32x4 a = Ks[l31 * 16 + ((2 * qq + half) ^ (l31 & 15))];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], qf[qq][j], s, 0, 0, 0);
+        }
+        // s[r] = S[query l31][key k0 + (r&3) + 8*(r>>2) + 4*half]
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = s[r] + Bias[(r & 3) + 8 * (r >> 2) + 4 * half];
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); ls += s[r]; }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float a0 = Vs[key * 64 + l31], a1 = Vs[key * 64 + 32 + l31];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], o1, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+        Os[wave][l31][d] = o0[r] / l_tot;
+        Os[wave][l31][d + 32] = o1[r] / l_tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = i * 64 + lane, row = idx >> 4, c = idx & 15;
+        if (q0w + row < t) {
+            f32x4 v;
+            v[0] = Os[wave][row][c * 4 + 0]; v[1] = Os[wave][row][c * 4 + 1];
+            v[2] = Os[wave][row][c * 4 + 2]; v[3] = Os[wave][row][c * 4 + 3];
+            *reinterpret_cast<f32x4*>(ctx + ((size_t)u * t + q0w + row) * hidden + h * 64 + c * 4) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder self-attention at position `pos` (model.py:588-600 with reserve_last; no mask).
+// One wave per (row, head); 16 lanes x 16 B cover one 64-float K or V row, 4 positions per pass.
+// The row's own k/v of position `pos` are appended to the cache (slot = the row's beam index);
+// history positions j < pos are read from slot anc[row][j] (see beam_step_kernel).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArgs a)
+{
+    if (*a.done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sc_all = reinterpret_cast<float*>(smem_raw);            // [4][width]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane >> 4, c = lane & 15;
+    const int hidden = a.heads * 64;
+    const int total = a.b * a.k * a.heads;
+    int g = blockIdx.x * 4 + wave;
+    const bool active = g < total;
+    if (!active) g = total - 1;
+    const int r = g / a.heads, h = g - r * a.heads;
+    const int u = r / a.k, slot = r - u * a.k;
+    const int pos = *a.pos;
+    const int32_t* anc = ((pos & 1) ? a.anc1 : a.anc0) + (size_t)r * a.width;
+    float* sc = sc_all + wave * a.width;
+
+    f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, v4 = q4;
+    {
+        const size_t rowoff = (size_t)r * 3 * hidden + h * 64 + c * 4;
+        for (int z = 0; z < a.nsplit; ++z) {
+            const float* p = a.qkv + z * a.split_stride + rowoff;
+            q4 += *reinterpret_cast<const f32x4*>(p);
+            k4 += *reinterpret_cast<const f32x4*>(p + hidden);
+            v4 += *reinterpret_cast<const f32x4*>(p + 2 * hidden);
+        }
+        const float* bp = a.bias + h * 64 + c * 4;
+        q4 += *reinterpret_cast<const f32x4*>(bp);
+        k4 += *reinterpret_cast<const f32x4*>(bp + hidden);
+        v4 += *reinterpret_cast<const f32x4*>(bp + 2 * hidden);
+        q4 = q4 * 0.125f;                                          // utils.py:628 (after the bias, Q3)
+    }
+    const size_t ubase = (size_t)u * a.width;
+    if (active && grp == 0) {
+        const size_t off = ((ubase + pos) * a.k + slot) * hidden + h * 64 + c * 4;
+        *reinterpret_cast<f32x4*>(a.kcache + off) = k4;
+        *reinterpret_cast<f32x4*>(a.vcache + off) = v4;
+    }
+
+    auto dot16 = [&](const f32x4& x, const f32x4& y) {
+        float d = (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+        d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
+        return d;
+    };
+
+    const float s_pos = dot16(q4, k4);
+    for (int j0 = 0; j0 < pos; j0 += 4) {
+        const int j = j0 + grp;
+        const bool valid = j < pos;
+        f32x4 kk = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            const int sl = anc[j];
+            kk = *reinterpret_cast<const f32x4*>(a.kcache + ((ubase + j) * a.k + sl) * hidden + h * 64 + c * 4);
+        }
+        const float d = dot16(q4, kk);
+        if (valid && c == 0) sc[j] = d;
+    }
+    __syncthreads();
+    float m = s_pos;
+    for (int j = lane; j < pos; j += 64) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < pos; j += 64) { const float e = expf(sc[j] - m); sc[j] = e; sum += e; }
+    const float e_pos = expf(s_pos - m);
+    sum = wave_sum(sum) + e_pos;
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < pos; j0 += 4) {
+        const int j = j0 + grp;
+        if (j < pos) {
+            const int sl = anc[j];
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(a.vcache + ((ubase + j) * a.k + sl) * hidden + h * 64 + c * 4);
+            acc += vv * (sc[j] / sum);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] += __shfl_xor(acc[j], 16); acc[j] += __shfl_xor(acc[j], 32); }
+    acc += v4 * (e_pos / sum);
+    if (active && grp == 0) *reinterpret_cast<f32x4*>(a.ctx + (size_t)r * hidden + h * 64 + c * 4) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder cross-attention (model.py:604-616): one workgroup per (utterance, head) serves all K beams.
+// K is stored transposed ([64][tp], built once per utterance by pack_cross_kv) so that lane = key
+// gives coalesced loads; V is [t][64] and is swept with 16 lanes x 16 B per key.
+// ------------------------------------------------------------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnArgs a)
+{
+    if (*a.done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* qs = reinterpret_cast<float*>(smem_raw);        // [KB][64]
+    float* red = qs + KB * 64;                             // [4][KB][64]
+    float* sc = red + 4 * KB * 64;                         // [KB][tp]
+    const int h = blockIdx.x, u = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hidden = a.heads * 64;
+    const int t = a.t, tp = a.tp, K = a.k;
+
+    for (int i = tid; i < KB * 16; i += 256) {
+        const int kb = i >> 4, c = i & 15;
+        f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+        if (kb < K) {
+            const size_t off = (size_t)(u * K + kb) * hidden + h * 64 + c * 4;
+            for (int z = 0; z < a.nsplit; ++z) q4 += *reinterpret_cast<const f32x4*>(a.qpart + z * a.split_stride + off);
+            q4 += *reinterpret_cast<const f32x4*>(a.qbias + h * 64 + c * 4);
+            q4 = q4 * 0.125f;
+        }
+        reinterpret_cast<f32x4*>(qs)[kb * 16 + c] = q4;
+    }
+    __syncthreads();
+
+    const float* kT = a.kT + ((size_t)u * a.heads + h) * 64 * tp;
+    for (int tt = tid; tt < tp; tt += 256) {
+        float acc[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc[kb] = 0.f;
+#pragma unroll 4
+        for (int d0 = 0; d0 < 64; d0 += 4) {
+            const float x0 = kT[(size_t)(d0 + 0) * tp + tt], x1 = kT[(size_t)(d0 + 1) * tp + tt];
+            const float x2 = kT[(size_t)(d0 + 2) * tp + tt], x3 = kT[(size_t)(d0 + 3) * tp + tt];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const f32x4 q4 = reinterpret_cast<const f32x4*>(qs)[kb * 16 + (d0 >> 2)];
+                acc[kb] = fmaf(q4[3], x3, fmaf(q4[2], x2, fmaf(q4[1], x1, fmaf(q4[0], x0, acc[kb]))));
+            }
+        }
+        const float bias = (tt >= t) ? -INFINITY : (a.pad2[(size_t)u * t + tt] ? -1e9f : 0.0f);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) sc[kb * tp + tt] = acc[kb] + bias;
+    }
+    __syncthreads();
+
+    for (int kb = wave; kb < K; kb += 4) {
+        float* s = sc + kb * tp;
+        float m = -INFINITY;
+        for (int tt = lane; tt < tp; tt += 64) m = fmaxf(m, s[tt]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int tt = lane; tt < tp; tt += 64) { const float e = expf(s[tt] - m); s[tt] = e; sum += e; }
+        sum = wave_sum(sum);
+        for (int tt = lane; tt < tp; tt += 64) s[tt] = s[tt] / sum;
+    }
+    __syncthreads();
+
+    const int grp = lane >> 4, c = lane & 15;
+    f32x4 o[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) o[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* vb = a.v + ((size_t)u * a.heads + h) * t * 64;
+    for (int tb = wave * 4; tb < t; tb += 16) {
+        const int tt = tb + grp;
+        if (tt < t) {
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (size_t)tt * 64 + c * 4);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) o[kb] += vv * sc[kb * tp + tt];
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[kb][j] += __shfl_xor(o[kb][j], 16); o[kb][j] += __shfl_xor(o[kb][j], 32); }
+        if (grp == 0) reinterpret_cast<f32x4*>(red)[(wave * KB + kb) * 16 + c] = o[kb];
+    }
+    __syncthreads();
+    for (int i = tid; i < KB * 16; i += 256) {
+        const int kb = i >> 4, cc = i & 15;
+        if (kb < K) {
+            const f32x4* rp = reinterpret_cast<const f32x4*>(red);
+            const f32x4 v = (rp[(0 * KB + kb) * 16 + cc] + rp[(1 * KB + kb) * 16 + cc]) +
+                            (rp[(2 * KB + kb) * 16 + cc] + rp[(3 * KB + kb) * 16 + cc]);
+            *reinterpret_cast<f32x4*>(a.ctx + (size_t)(u * K + kb) * hidden + h * 64 + cc * 4) = v;
+        }
+    }
+}
+
+int cross_kb(int k) { return k <= 1 ? 1 : k <= 2 ? 2 : k <= 4 ? 4 : k <= 8 ? 8 : k <= 12 ? 12 : k <= 16 ? 16 : 32; }
+
+template <int KB>
+hipError_t launch_cross(const CrossAttnArgs& a, size_t lds, hipStream_t s)
+{
+    auto kern = decoder_cross_attention_kernel<KB>;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.heads, a.b), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads, float* ctx, hipStream_t s)
+{
+    if (n <= 0 || t <= 0) return hipSuccess;
+    hipLaunchKernelGGL(encoder_attention_kernel, dim3((t + 127) / 128, heads, n), dim3(256), 0, s, qkv, pad, t, heads, ctx);
+    return hipGetLastError();
+}
+
+hipError_t launch_decoder_self_attention(const SelfAttnArgs& a, hipStream_t s)
+{
+    const int total = a.b * a.k * a.heads;
+    if (total <= 0) return hipSuccess;
+    const size_t lds = (size_t)4 * a.width * sizeof(float);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decoder_self_attention_kernel, dim3((total + 3) / 4), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+size_t cross_attention_lds_bytes(int k, int tp)
+{
+    const int kb = cross_kb(k);
+    return ((size_t)kb * 64 * 5 + (size_t)kb * tp) * sizeof(float);
+}
+
+hipError_t launch_decoder_cross_attention(const CrossAttnArgs& a, hipStream_t s)
+{
+    if (a.b <= 0) return hipSuccess;
+    const size_t lds = cross_attention_lds_bytes(a.k, a.tp);
+    if (lds > 150 * 1024 || a.k > ASR_MAX_BEAM) return hipErrorInvalidValue;
+    switch (cross_kb(a.k)) {
+        case 1: return launch_cross<1>(a, lds, s);
+        case 2: return launch_cross<2>(a, lds, s);
+        case 4: return launch_cross<4>(a, lds, s);
+        case 8: return launch_cross<8>(a, lds, s);
+        case 12: return launch_cross<12>(a, lds, s);
+        case 16: return launch_cross<16>(a, lds, s);
+        default: return launch_cross<32>(a, lds, s);
+    }
+}

@@ -1,0 +1,1117 @@
+// libasr_amd.so -- handle, weight store, workspaces, encoder / beam-search orchestration and the
+// C ABI of include/asr_amd.h.  One handle = one GPU.  Reference citations are relative to
+// /root/reference/transformer/.
+#include "asr_common.h"
+#include "../../include/asr_amd.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct ProfClass {
+    const char* name;
+    double ms = 0.0;
+    int64_t launches = 0;
+    double flops = 0.0, bytes = 0.0;
+};
+
+struct EncBlock {
+    float *wqkv, *bqkv, *wo, *bo, *ln0s, *ln0b, *w1, *b1, *w2, *b2, *ln1s, *ln1b;
+};
+struct DecBlock {
+    float *wqkv, *bqkv, *wo, *bo, *ln0s, *ln0b;
+    float *wq, *bq, *wkv, *bkv, *wco, *bco, *ln1s, *ln1b;
+    float *w1, *b1, *w2, *b2, *ln2s, *ln2b;
+};
+
+}  // namespace
+
+struct asr_handle {
+    asr_config cfg;
+    int H = 0, heads = 0, L = 0, V = 0, D = 0, F = 0, K = 0;
+    bool glu = false;
+    int ff_epi = EPI_RELU;
+    hipStream_t stream = nullptr;
+    mutable std::string err;
+    std::map<std::string, HostTensor> staged;
+    bool finalized = false;
+
+    std::map<void*, size_t> allocs;     // everything hipMalloc'ed through dev_alloc -> bytes
+    int64_t dev_bytes = 0;
+
+    // weights
+    float *w_src = nullptr, *b_src = nullptr, *in_gamma = nullptr, *in_beta = nullptr;
+    float *emb = nullptr, *softmax_w = nullptr;
+    std::vector<EncBlock> enc;
+    std::vector<DecBlock> dec;
+    float* pe = nullptr;
+    int pe_rows = 0;
+
+    // encoder workspaces (capacity in rows = n*t)
+    size_t cap_rows = 0;
+    int cap_n = 0, cap_t = 0;
+    float *xin = nullptr, *x0 = nullptr, *x1 = nullptr, *x2 = nullptr, *x3 = nullptr, *qkv = nullptr, *hid = nullptr;
+    int32_t *pad = nullptr, *pad2 = nullptr;
+    double* norm_scratch = nullptr;
+    std::vector<float*> cross_kT, cross_v;
+    int cross_tp = 0;
+
+    // decoder workspaces (capacity in rows = n*K)
+    int cap_dec_n = 0;
+    float *y0 = nullptr, *z1 = nullptr, *z2 = nullptr, *dctx = nullptr, *part = nullptr, *dhid = nullptr, *logits = nullptr;
+    float* cand_scores = nullptr;
+    int32_t* cand_tokens = nullptr;
+    std::vector<float*> kcache, vcache;
+    BeamState beam{};
+    int32_t* done_host = nullptr;       // pinned
+    std::vector<hipEvent_t> step_events;
+
+    // profile
+    int profile = 0;
+    std::vector<ProfClass> prof;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e__ = (expr);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                            \
+            return ASR_ERR_HIP;                                                                       \
+        }                                                                                             \
+    } while (0)
+
+int fail(asr_handle* h, int code, const std::string& msg)
+{
+    h->err = msg;
+    return code;
+}
+
+int dev_alloc(asr_handle* h, void** p, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(h, hipMalloc(p, bytes));
+    h->allocs[*p] = bytes;
+    h->dev_bytes += (int64_t)bytes;
+    return ASR_OK;
+}
+
+void dev_free(asr_handle* h, void* p)
+{
+    if (!p) return;
+    auto it = h->allocs.find(p);
+    if (it != h->allocs.end()) { h->dev_bytes -= (int64_t)it->second; h->allocs.erase(it); }
+    (void)hipFree(p);
+}
+
+template <typename T>
+int dev_alloc_t(asr_handle* h, T** p, size_t count)
+{
+    return dev_alloc(h, reinterpret_cast<void**>(p), count * sizeof(T));
+}
+
+// ---- profile brackets -----------------------------------------------------------------------
+struct ProfScope {
+    asr_handle* h;
+    ProfClass* pc = nullptr;
+    ProfScope(asr_handle* h_, const char* name, double flops, double bytes) : h(h_)
+    {
+        if (!h->profile) return;
+        for (auto& c : h->prof)
+            if (c.name == name || strcmp(c.name, name) == 0) { pc = &c; break; }
+        if (!pc) {
+            h->prof.push_back(ProfClass{name});
+            pc = &h->prof.back();
+        }
+        pc->flops += flops;
+        pc->bytes += bytes;
+        pc->launches += 1;
+        (void)hipEventRecord(h->pe0, h->stream);
+    }
+    ~ProfScope()
+    {
+        if (!pc) return;
+        (void)hipEventRecord(h->pe1, h->stream);
+        (void)hipEventSynchronize(h->pe1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, h->pe0, h->pe1);
+        pc->ms += ms;
+    }
+};
+
+const char* gemm_class_name(int M, int N, int epilogue)
+{
+    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const bool big = tiles128 >= 512;
+    switch (epilogue) {
+        case EPI_GLU: return big ? "gemm_f32_nt<128,128,GLU>" : "gemm_f32_nt<64,128,GLU>";
+        case EPI_PARTIAL: return big ? "gemm_f32_nt<128,128,PARTIAL>" : "gemm_f32_nt<64,64,PARTIAL>";
+        case EPI_BIAS: return big ? "gemm_f32_nt<128,128,BIAS>" : "gemm_f32_nt<64,64,BIAS>";
+        default: return big ? "gemm_f32_nt<128,128,ACT>" : "gemm_f32_nt<64,64,ACT>";
+    }
+}
+
+int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epilogue,
+         int split_k)
+{
+    GemmArgs a{};
+    a.A = A; a.W = W; a.bias = bias; a.C = C;
+    a.M = M; a.N = N; a.K = K;
+    a.lda = K; a.ldw = K;
+    a.ldc = (epilogue == EPI_GLU) ? N / 2 : N;
+    a.split_k = split_k;
+    a.epilogue = epilogue;
+    const double nout = (epilogue == EPI_GLU) ? N / 2.0 : (double)N * split_k;
+    ProfScope ps(h, gemm_class_name(M, N, epilogue), 2.0 * M * N * (double)K,
+                 4.0 * ((double)M * K + (double)N * K + (double)M * nout));
+    HIP_TRY(h, launch_gemm_f32(a, 0, h->stream));
+    return ASR_OK;
+}
+
+// ---- timing signal table (third_party/tensor2tensor/common_attention.py:28-69), evaluated with
+// correctly rounded float32 elementary functions in the graph's op order -----------------------
+std::vector<float> timing_table(int rows, int channels)
+{
+    std::vector<float> t((size_t)rows * channels, 0.f);
+    const int nts = channels / 2;
+    const float inc = (float)log(1.0e5 / 1.0) / ((float)nts - 1.0f);
+    std::vector<float> inv(nts);
+    for (int j = 0; j < nts; ++j) inv[j] = 1.0f * (float)exp((double)((float)j * -inc));
+    for (int p = 0; p < rows; ++p)
+        for (int j = 0; j < nts; ++j) {
+            const float st = (float)p * inv[j];
+            t[(size_t)p * channels + j] = (float)sin((double)st);
+            t[(size_t)p * channels + nts + j] = (float)cos((double)st);
+        }
+    return t;
+}
+
+int ensure_pe(asr_handle* h, int rows)
+{
+    if (rows <= h->pe_rows) return ASR_OK;
+    rows = std::max(rows, 512);
+    if (h->pe) dev_free(h, h->pe);
+    h->pe = nullptr;
+    std::vector<float> t = timing_table(rows, h->H);
+    int rc = dev_alloc_t(h, &h->pe, t.size());
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(h->pe, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->pe_rows = rows;
+    return ASR_OK;
+}
+
+// ---- variable table -----------------------------------------------------------------
+struct VarSpec { std::string name; std::vector<int64_t> shape; };
+
+std::vector<VarSpec> required_vars(const asr_handle* h)
+{
+    const int64_t H = h->H, D = h->D, V = h->V, F = h->F;
+    std::vector<VarSpec> v;
+    auto add = [&](const std::string& n, std::vector<int64_t> s) { v.push_back({n, std::move(s)}); };
+    add("encoder/src_change/kernel", {H, D});
+    add("encoder/src_change/bias", {H});
+    add("encoder/LayerNorm/beta", {H});
+    add("encoder/LayerNorm/gamma", {H});
+    auto ffn = [&](const std::string& p) {
+        if (h->glu) {
+            add(p + "/ff_hidden/dense/arg1/kernel", {F, H}); add(p + "/ff_hidden/dense/arg1/bias", {F});
+            add(p + "/ff_hidden/dense/arg2/kernel", {F, H}); add(p + "/ff_hidden/dense/arg2/bias", {F});
+        } else {
+            add(p + "/ff_hidden/dense/kernel", {F, H}); add(p + "/ff_hidden/dense/bias", {F});
+        }
+        add(p + "/ff_hidden/dense_1/kernel", {H, F}); add(p + "/ff_hidden/dense_1/bias", {H});
+    };
+    auto ln = [&](const std::string& p, const char* n) {
+        add(p + "/" + n + "/layer_norm_scale", {H}); add(p + "/" + n + "/layer_norm_bias", {H});
+    };
+    for (int i = 0; i < h->L; ++i) {
+        const std::string p = "encoder/block_" + std::to_string(i);
+        add(p + "/encoder_self_attention/qkv_transform/kernel", {3 * H, H});
+        add(p + "/encoder_self_attention/qkv_transform/bias", {3 * H});
+        add(p + "/encoder_self_attention/output_transform/kernel", {H, H});
+        add(p + "/encoder_self_attention/output_transform/bias", {H});
+        ffn(p); ln(p, "layer_norm"); ln(p, "layer_norm_1");
+    }
+    add("decoder/dst_embedding/kernel", {V, H});
+    if (!h->cfg.tie_embedding_and_softmax) add("decoder/softmax/kernel", {V, H});
+    for (int i = 0; i < h->L; ++i) {
+        const std::string p = "decoder/block_" + std::to_string(i);
+        add(p + "/decoder_self_attention/qkv_transform/kernel", {3 * H, H});
+        add(p + "/decoder_self_attention/qkv_transform/bias", {3 * H});
+        add(p + "/decoder_self_attention/output_transform/kernel", {H, H});
+        add(p + "/decoder_self_attention/output_transform/bias", {H});
+        add(p + "/decoder_vanilla_attention/q_transform/kernel", {H, H});
+        add(p + "/decoder_vanilla_attention/q_transform/bias", {H});
+        add(p + "/decoder_vanilla_attention/kv_transform/kernel", {2 * H, H});
+        add(p + "/decoder_vanilla_attention/kv_transform/bias", {2 * H});
+        add(p + "/decoder_vanilla_attention/output_transform/kernel", {H, H});
+        add(p + "/decoder_vanilla_attention/output_transform/bias", {H});
+        ffn(p); ln(p, "layer_norm"); ln(p, "layer_norm_1"); ln(p, "layer_norm_2");
+    }
+    return v;
+}
+
+bool is_ignored_var(const std::string& n)
+{
+    auto ends_with = [&](const char* s) { const size_t l = strlen(s); return n.size() >= l && n.compare(n.size() - l, l, s) == 0; };
+    return ends_with("/Adam") || ends_with("/Adam_1") || n == "beta1_power" || n == "beta2_power" ||
+           n.compare(0, 11, "global_step") == 0;
+}
+
+int upload(asr_handle* h, const std::string& name, float** dst)
+{
+    const HostTensor& t = h->staged.at(name);
+    int rc = dev_alloc_t(h, dst, t.data.size());
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(*dst, t.data.data(), t.data.size() * sizeof(float), hipMemcpyHostToDevice));
+    return ASR_OK;
+}
+
+// ff_hidden first dense: GLU weights packed [2F][H] in groups of 32 rows: value rows | gate rows
+int upload_ffn1(asr_handle* h, const std::string& p, float** w, float** b)
+{
+    if (!h->glu) {
+        int rc = upload(h, p + "/ff_hidden/dense/kernel", w);
+        if (rc) return rc;
+        return upload(h, p + "/ff_hidden/dense/bias", b);
+    }
+    const HostTensor& w1 = h->staged.at(p + "/ff_hidden/dense/arg1/kernel");
+    const HostTensor& w2 = h->staged.at(p + "/ff_hidden/dense/arg2/kernel");
+    const HostTensor& b1 = h->staged.at(p + "/ff_hidden/dense/arg1/bias");
+    const HostTensor& b2 = h->staged.at(p + "/ff_hidden/dense/arg2/bias");
+    const int F = h->F, H = h->H;
+    std::vector<float> wp((size_t)2 * F * H), bp((size_t)2 * F);
+    for (int g = 0; g < F / 32; ++g)
+        for (int r = 0; r < 32; ++r) {
+            memcpy(&wp[((size_t)g * 64 + r) * H], &w1.data[((size_t)g * 32 + r) * H], (size_t)H * sizeof(float));
+            memcpy(&wp[((size_t)g * 64 + 32 + r) * H], &w2.data[((size_t)g * 32 + r) * H], (size_t)H * sizeof(float));
+            bp[(size_t)g * 64 + r] = b1.data[(size_t)g * 32 + r];
+            bp[(size_t)g * 64 + 32 + r] = b2.data[(size_t)g * 32 + r];
+        }
+    int rc = dev_alloc_t(h, w, wp.size());
+    if (rc) return rc;
+    rc = dev_alloc_t(h, b, bp.size());
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(*w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(*b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+    return ASR_OK;
+}
+
+// ---- workspaces -------------------------------------------------------------------------------
+int ensure_encoder_capacity(asr_handle* h, int n, int t)
+{
+    const size_t rows = (size_t)n * t;
+    const int tp = (t + 63) / 64 * 64;
+    if (rows <= h->cap_rows && n <= h->cap_n && tp <= h->cross_tp) return ASR_OK;
+    const size_t nrows = std::max(rows, h->cap_rows);
+    const int nn = std::max(n, h->cap_n), ntp = std::max(tp, h->cross_tp);
+    float** bufs[] = {&h->xin, &h->x0, &h->x1, &h->x2, &h->x3, &h->qkv, &h->hid};
+    for (auto b : bufs) { dev_free(h, *b); *b = nullptr; }
+    dev_free(h, h->pad); dev_free(h, h->pad2); dev_free(h, h->norm_scratch);
+    h->pad = h->pad2 = nullptr; h->norm_scratch = nullptr;
+    for (auto p : h->cross_kT) dev_free(h, p);
+    for (auto p : h->cross_v) dev_free(h, p);
+    h->cross_kT.assign(h->L, nullptr);
+    h->cross_v.assign(h->L, nullptr);
+    // rows capacity must also cover nn * ntp-ish packing of cross K/V: size those by nn*ntp
+    const size_t H = h->H;
+    int rc = 0;
+    rc |= dev_alloc_t(h, &h->xin, nrows * (size_t)h->D);
+    rc |= dev_alloc_t(h, &h->x0, nrows * H);
+    rc |= dev_alloc_t(h, &h->x1, nrows * H);
+    rc |= dev_alloc_t(h, &h->x2, nrows * H);
+    rc |= dev_alloc_t(h, &h->x3, nrows * H);
+    rc |= dev_alloc_t(h, &h->qkv, nrows * 3 * H);
+    rc |= dev_alloc_t(h, &h->hid, nrows * (size_t)h->F);
+    rc |= dev_alloc_t(h, &h->pad, nrows);
+    rc |= dev_alloc_t(h, &h->pad2, nrows);
+    rc |= dev_alloc_t(h, &h->norm_scratch, input_norm_scratch_doubles(nn, 0, 0));
+    const size_t cross_elems = std::max(nrows, (size_t)nn * ntp) * H + (size_t)nn * 64 * H;   // kT rows padded to tp
+    for (int l = 0; l < h->L && !rc; ++l) {
+        rc |= dev_alloc_t(h, &h->cross_kT[l], cross_elems);
+        rc |= dev_alloc_t(h, &h->cross_v[l], nrows * H);
+    }
+    if (rc) return ASR_ERR_HIP;
+    h->cap_rows = nrows; h->cap_n = nn; h->cross_tp = ntp;
+    return ASR_OK;
+}
+
+int decode_splits(const asr_handle* h, int R, int* s_qkv, int* s_proj, int* s_ffn2)
+{
+    *s_qkv = gemm_pick_split_k(R, 3 * h->H, h->H);
+    *s_proj = gemm_pick_split_k(R, h->H, h->H);
+    *s_ffn2 = gemm_pick_split_k(R, h->H, h->F);
+    return 0;
+}
+
+int ensure_decoder_capacity(asr_handle* h, int n)
+{
+    if (n <= h->cap_dec_n) return ASR_OK;
+    const size_t R = (size_t)n * h->K, H = h->H;
+    const int width = h->cfg.max_target_length + 2;
+    float** bufs[] = {&h->y0, &h->z1, &h->z2, &h->dctx, &h->part, &h->dhid, &h->logits, &h->cand_scores};
+    for (auto b : bufs) { dev_free(h, *b); *b = nullptr; }
+    dev_free(h, h->cand_tokens); h->cand_tokens = nullptr;
+    for (auto p : h->kcache) dev_free(h, p);
+    for (auto p : h->vcache) dev_free(h, p);
+    h->kcache.assign(h->L, nullptr);
+    h->vcache.assign(h->L, nullptr);
+    void* bs[] = {h->beam.scores[0], h->beam.scores[1], h->beam.finished[0], h->beam.finished[1], h->beam.preds[0],
+                  h->beam.preds[1], h->beam.anc[0], h->beam.anc[1], h->beam.pos, h->beam.tokens, h->beam.parents};
+    for (auto p : bs) dev_free(h, p);
+    h->beam = BeamState{};
+
+    int rc = 0;
+    rc |= dev_alloc_t(h, &h->y0, R * H);
+    rc |= dev_alloc_t(h, &h->z1, R * H);
+    rc |= dev_alloc_t(h, &h->z2, R * H);
+    rc |= dev_alloc_t(h, &h->dctx, R * H);
+    rc |= dev_alloc_t(h, &h->part, (size_t)ASR_MAX_SPLITK * R * 3 * H);
+    rc |= dev_alloc_t(h, &h->dhid, R * (size_t)h->F);
+    rc |= dev_alloc_t(h, &h->logits, R * (size_t)h->V);
+    rc |= dev_alloc_t(h, &h->cand_scores, R * (size_t)h->K);
+    rc |= dev_alloc_t(h, &h->cand_tokens, R * (size_t)h->K);
+    for (int l = 0; l < h->L && !rc; ++l) {
+        rc |= dev_alloc_t(h, &h->kcache[l], R * width * H);
+        rc |= dev_alloc_t(h, &h->vcache[l], R * width * H);
+    }
+    for (int i = 0; i < 2 && !rc; ++i) {
+        rc |= dev_alloc_t(h, &h->beam.scores[i], R);
+        rc |= dev_alloc_t(h, &h->beam.finished[i], R);
+        rc |= dev_alloc_t(h, &h->beam.preds[i], R * width);
+        rc |= dev_alloc_t(h, &h->beam.anc[i], R * width);
+    }
+    rc |= dev_alloc_t(h, &h->beam.pos, 4);
+    rc |= dev_alloc_t(h, &h->beam.tokens, R);
+    rc |= dev_alloc_t(h, &h->beam.parents, R);
+    if (rc) return ASR_ERR_HIP;
+    h->beam.done = h->beam.pos + 1;
+    h->beam.unfinished = h->beam.pos + 2;
+    h->beam.width = width;
+    h->cap_dec_n = n;
+    return ASR_OK;
+}
+
+// ---- encoder (model.py:444-490) ----------------------------------------------------------------
+// X_dev [n, t, D] -> h->x0 [n*t, H] (encoder output), h->pad / h->pad2 [n*t]
+int run_encoder(asr_handle* h, const float* X_dev, int n, int t)
+{
+    const int M = n * t, H = h->H, F = h->F;
+    int rc = ensure_pe(h, std::max(t, h->cfg.max_target_length + 2));
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    {
+        ProfScope ps(h, "pad_mask", 0, 4.0 * M * (h->D + 1));
+        HIP_TRY(h, launch_pad_mask(X_dev, M, h->D, h->pad, s));
+    }
+    rc = gemm(h, X_dev, h->w_src, h->b_src, h->x1, M, H, h->D, EPI_BIAS, 1);                        // :451
+    if (rc) return rc;
+    {
+        ProfScope ps(h, "input_norm_timing", 0, 4.0 * M * H * 4.0);
+        HIP_TRY(h, launch_input_norm_timing(h->x1, h->in_gamma, h->in_beta, h->pe, n, t, H, h->norm_scratch, h->x0, s));   // :453,456
+    }
+    for (int l = 0; l < h->L; ++l) {
+        const EncBlock& b = h->enc[l];
+        const bool last = (l == h->L - 1);
+        rc = gemm(h, h->x0, b.wqkv, b.bqkv, h->qkv, M, 3 * H, H, EPI_BIAS, 1);                      // utils.py:612
+        if (rc) return rc;
+        {
+            ProfScope ps(h, "encoder_attention", 4.0 * n * (double)t * t * H, 4.0 * M * 4.0 * H);
+            HIP_TRY(h, launch_encoder_attention(h->qkv, h->pad, n, t, h->heads, h->x1, s));         // utils.py:624-631
+        }
+        rc = gemm(h, h->x1, b.wo, nullptr, h->x2, M, H, H, EPI_PARTIAL, 1);                         // utils.py:632
+        if (rc) return rc;
+        {
+            ProfScope ps(h, "add_layer_norm", 0, 4.0 * M * H * 3.0);
+            HIP_TRY(h, launch_add_layer_norm(h->x0, h->x2, 1, 0, b.bo, b.ln0s, b.ln0b, nullptr, nullptr, M, H, h->x3, s));   // model.py:466
+        }
+        rc = gemm(h, h->x3, b.w1, b.b1, h->hid, M, h->glu ? 2 * F : F, H, h->glu ? EPI_GLU : h->ff_epi, 1);   // utils.py:566
+        if (rc) return rc;
+        rc = gemm(h, h->hid, b.w2, nullptr, h->x2, M, H, F, EPI_PARTIAL, 1);                        // utils.py:567
+        if (rc) return rc;
+        {
+            ProfScope ps(h, "add_layer_norm", 0, 4.0 * M * H * 3.0);
+            HIP_TRY(h, launch_add_layer_norm(h->x3, h->x2, 1, 0, b.b2, b.ln1s, b.ln1b, last ? h->pad : nullptr,
+                                             last ? h->pad2 : nullptr, M, H, h->x0, s));            // model.py:481,489
+        }
+    }
+    return ASR_OK;
+}
+
+// cross-attention K/V of every decoder block, once per utterance (instead of once per step per beam)
+int run_cross_kv(asr_handle* h, int n, int t)
+{
+    const int M = n * t, H = h->H;
+    const int tp = (t + 63) / 64 * 64;
+    for (int l = 0; l < h->L; ++l) {
+        int rc = gemm(h, h->x0, h->dec[l].wkv, h->dec[l].bkv, h->qkv, M, 2 * H, H, EPI_BIAS, 1);   // utils.py:618
+        if (rc) return rc;
+        ProfScope ps(h, "pack_cross_kv", 0, 4.0 * M * 4.0 * H);
+        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, tp, h->heads, h->cross_kT[l], h->cross_v[l], h->stream));
+    }
+    return ASR_OK;
+}
+
+// one decode step (model.py:270-303 with decoder_with_caching_impl :559-633 restated on a K/V cache)
+int run_decode_step(asr_handle* h, int n, int t)
+{
+    const int R = n * h->K, H = h->H, F = h->F, K = h->K;
+    const int tp = (t + 63) / 64 * 64;
+    hipStream_t s = h->stream;
+    const BeamState& st = h->beam;
+    int s_qkv, s_proj, s_ffn2;
+    decode_splits(h, R, &s_qkv, &s_proj, &s_ffn2);
+    const size_t RH = (size_t)R * H;
+    const float mult = h->cfg.scale_embedding ? (float)sqrt((double)H) : 1.0f;
+    {
+        ProfScope ps(h, "embed_pe", 0, 4.0 * R * H * 3.0);
+        HIP_TRY(h, launch_embed_pe(h->emb, st.preds[0], st.preds[1], st.width, st.pos, h->pe, mult, R, H, h->y0, st.done, s));
+    }
+    for (int l = 0; l < h->L; ++l) {
+        const DecBlock& b = h->dec[l];
+        int rc = gemm(h, h->y0, b.wqkv, nullptr, h->part, R, 3 * H, H, EPI_PARTIAL, s_qkv);
+        if (rc) return rc;
+        {
+            SelfAttnArgs a{};
+            a.qkv = h->part; a.nsplit = s_qkv; a.split_stride = 3 * RH; a.bias = b.bqkv;
+            a.kcache = h->kcache[l]; a.vcache = h->vcache[l];
+            a.anc0 = st.anc[0]; a.anc1 = st.anc[1]; a.pos = st.pos; a.done = st.done;
+            a.ctx = h->dctx; a.b = n; a.k = K; a.heads = h->heads; a.width = st.width;
+            ProfScope ps(h, "decoder_self_attention", 0, 0);
+            HIP_TRY(h, launch_decoder_self_attention(a, s));
+        }
+        rc = gemm(h, h->dctx, b.wo, nullptr, h->part, R, H, H, EPI_PARTIAL, s_proj);
+        if (rc) return rc;
+        {
+            ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + s_proj));
+            HIP_TRY(h, launch_add_layer_norm_done(h->y0, h->part, s_proj, RH, b.bo, b.ln0s, b.ln0b, nullptr, nullptr, R, H,
+                                                  h->z1, st.done, s));
+        }
+        rc = gemm(h, h->z1, b.wq, nullptr, h->part, R, H, H, EPI_PARTIAL, s_proj);
+        if (rc) return rc;
+        {
+            CrossAttnArgs a{};
+            a.qpart = h->part; a.nsplit = s_proj; a.split_stride = RH; a.qbias = b.bq;
+            a.kT = h->cross_kT[l]; a.v = h->cross_v[l]; a.pad2 = h->pad2; a.done = st.done;
+            a.ctx = h->dctx; a.b = n; a.k = K; a.heads = h->heads; a.t = t; a.tp = tp;
+            ProfScope ps(h, "decoder_cross_attention", 4.0 * R * (double)t * H, 4.0 * 2.0 * n * (double)t * H);
+            HIP_TRY(h, launch_decoder_cross_attention(a, s));
+        }
+        rc = gemm(h, h->dctx, b.wco, nullptr, h->part, R, H, H, EPI_PARTIAL, s_proj);
+        if (rc) return rc;
+        {
+            ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + s_proj));
+            HIP_TRY(h, launch_add_layer_norm_done(h->z1, h->part, s_proj, RH, b.bco, b.ln1s, b.ln1b, nullptr, nullptr, R, H,
+                                                  h->z2, st.done, s));
+        }
+        rc = gemm(h, h->z2, b.w1, b.b1, h->dhid, R, h->glu ? 2 * F : F, H, h->glu ? EPI_GLU : h->ff_epi, 1);
+        if (rc) return rc;
+        rc = gemm(h, h->dhid, b.w2, nullptr, h->part, R, H, F, EPI_PARTIAL, s_ffn2);
+        if (rc) return rc;
+        {
+            ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + s_ffn2));
+            HIP_TRY(h, launch_add_layer_norm_done(h->z2, h->part, s_ffn2, RH, b.b2, b.ln2s, b.ln2b, nullptr, nullptr, R, H,
+                                                  h->y0, st.done, s));
+        }
+    }
+    const float* wout = h->cfg.tie_embedding_and_softmax ? h->emb : h->softmax_w;
+    int rc = gemm(h, h->y0, wout, nullptr, h->logits, R, h->V, H, EPI_BIAS, 1);                     // model.py:341
+    if (rc) return rc;
+    {
+        ProfScope ps(h, "log_softmax_topk", 0, 4.0 * R * (double)h->V);
+        HIP_TRY(h, launch_log_softmax_topk(h->logits, R, h->V, K, h->cand_scores, h->cand_tokens, st.done, s));   // :345-346
+    }
+    {
+        ProfScope ps(h, "beam_step", 0, 0);
+        HIP_TRY(h, launch_beam_step(st, h->cand_scores, h->cand_tokens, n, K, s));                  // :280-301
+    }
+    return ASR_OK;
+}
+
+// model.py:325-336 on the host (a [n, K] problem): GNMT length penalty incl. the leading <S>, first argmax
+void finalize_host(const int32_t* preds, const float* scores, int n, int K, int width, int len, float alpha, int32_t* Y)
+{
+    for (int u = 0; u < n; ++u) {
+        int best = 0;
+        float bestv = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const int32_t* p = preds + (size_t)(u * K + k) * width;
+            int cnt = 0;
+            for (int j = 0; j <= len; ++j) cnt += (p[j] != 3);
+            const float lp = powf((5.0f + (float)cnt) / 6.0f, alpha);
+            const float v = scores[u * K + k] / lp;
+            if (k == 0 || v > bestv) { bestv = v; best = k; }
+        }
+        const int32_t* p = preds + (size_t)(u * K + best) * width;
+        for (int j = 0; j < len; ++j) Y[(size_t)u * len + j] = p[1 + j];
+    }
+}
+
+struct TraceOut { int steps = 0; float* logits = nullptr; float* scores = nullptr; int32_t* tokens = nullptr; int32_t* parents = nullptr; };
+
+// X_dev [n,t,D] on device (already stacked) -> Y host
+int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int64_t y_capacity, int32_t* len_out,
+                const TraceOut* tr)
+{
+    if (!h->finalized) return fail(h, ASR_ERR_STATE, "asr_finalize_weights has not succeeded on this handle");
+    if (n == 0) { *len_out = 0; return ASR_OK; }                                                    // model.py:184-187
+    int rc = ensure_decoder_capacity(h, n);
+    if (rc) return rc;
+    rc = run_encoder(h, X_dev, n, t);
+    if (rc) return rc;
+    rc = run_cross_kv(h, n, t);
+    if (rc) return rc;
+    const int K = h->K, R = n * K;
+    h->beam.limit = std::min(t + 50, (int)h->cfg.max_target_length);                                // :310 (Q7)
+    const int max_steps = h->beam.limit + 1;
+    HIP_TRY(h, launch_beam_init(h->beam, n, K, h->stream));
+    constexpr int LOOKAHEAD = 3;
+    int launched = 0;
+    for (int s = 1; s <= max_steps; ++s) {
+        rc = run_decode_step(h, n, t);
+        if (rc) return rc;
+        launched = s;
+        if (tr && s <= tr->steps) {
+            const int buf = s & 1;
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            int32_t posd[2];
+            HIP_TRY(h, hipMemcpy(posd, h->beam.pos, sizeof(posd), hipMemcpyDeviceToHost));
+            if (posd[0] == s) {                                                                     // the step really ran
+                if (tr->logits) HIP_TRY(h, hipMemcpy(tr->logits + (size_t)(s - 1) * R * h->V, h->logits, (size_t)R * h->V * 4, hipMemcpyDeviceToHost));
+                if (tr->scores) HIP_TRY(h, hipMemcpy(tr->scores + (size_t)(s - 1) * R, h->beam.scores[buf], (size_t)R * 4, hipMemcpyDeviceToHost));
+                if (tr->tokens) HIP_TRY(h, hipMemcpy(tr->tokens + (size_t)(s - 1) * R, h->beam.tokens, (size_t)R * 4, hipMemcpyDeviceToHost));
+                if (tr->parents) HIP_TRY(h, hipMemcpy(tr->parents + (size_t)(s - 1) * R, h->beam.parents, (size_t)R * 4, hipMemcpyDeviceToHost));
+            }
+        }
+        HIP_TRY(h, hipMemcpyAsync(&h->done_host[s], h->beam.done, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipEventRecord(h->step_events[s % 8], h->stream));
+        if (s > LOOKAHEAD) {
+            const int c = s - LOOKAHEAD;
+            HIP_TRY(h, hipEventSynchronize(h->step_events[c % 8]));
+            if (h->done_host[c]) break;
+        }
+    }
+    (void)launched;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int32_t posd[2] = {0, 0};
+    HIP_TRY(h, hipMemcpy(posd, h->beam.pos, sizeof(posd), hipMemcpyDeviceToHost));
+    const int len = posd[0];
+    if (!posd[1] || len < 1 || len > max_steps) return fail(h, ASR_ERR_HIP, "beam search loop ended in an inconsistent state");
+    if ((int64_t)n * len > y_capacity) return fail(h, ASR_ERR_CAPACITY, "Y too small: need n * " + std::to_string(len) + " int32");
+    const int width = h->beam.width, buf = len & 1;
+    std::vector<int32_t> preds((size_t)R * width);
+    std::vector<float> scores(R);
+    HIP_TRY(h, hipMemcpy(preds.data(), h->beam.preds[buf], preds.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(scores.data(), h->beam.scores[buf], scores.size() * 4, hipMemcpyDeviceToHost));
+    finalize_host(preds.data(), scores.data(), n, K, width, len, h->cfg.lp_alpha, Y);
+    *len_out = len;
+    return ASR_OK;
+}
+
+int check_xshape(asr_handle* h, int n, int t, int d)
+{
+    if (n < 0 || t < 0 || d != h->D) return fail(h, ASR_ERR_ARG, "X must be [n, t, input_dim=" + std::to_string(h->D) + "]");
+    if (n > 0 && t < 1) return fail(h, ASR_ERR_ARG, "t must be >= 1");
+    if ((size_t)((t + 63) / 64 * 64) * h->K * 4 + (size_t)h->K * 64 * 5 * 4 + 4096 > 150 * 1024)
+        return fail(h, ASR_ERR_ARG, "t * beam_size exceeds the cross-attention LDS budget");
+    return ASR_OK;
+}
+
+int set_device(asr_handle* h)
+{
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return ASR_OK;
+}
+
+struct TmpBufs {
+    std::vector<void*> p;
+    ~TmpBufs() { for (void* q : p) (void)hipFree(q); }
+    template <typename T>
+    hipError_t up(T** d, const T* src, size_t count, hipStream_t s)
+    {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(d), std::max<size_t>(count * sizeof(T), 16));
+        if (e != hipSuccess) return e;
+        p.push_back(*d);
+        if (src) e = hipMemcpyAsync(*d, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+        return e;
+    }
+};
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int asr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int asr_create(const asr_config* cfg, asr_handle** out)
+{
+    if (!cfg || !out) { g_create_error = "null argument"; return ASR_ERR_ARG; }
+    *out = nullptr;
+    auto bad = [&](const std::string& m) { g_create_error = m; return (int)ASR_ERR_ARG; };
+    if (cfg->hidden_units <= 0 || cfg->num_heads <= 0 || cfg->hidden_units != cfg->num_heads * ASR_D_HEAD)
+        return bad("hidden_units / num_heads must be 64");
+    if (cfg->hidden_units > 2048 || (cfg->hidden_units & 63)) return bad("hidden_units must be a multiple of 64, <= 2048");
+    if (cfg->input_dim <= 0 || (cfg->input_dim & 3)) return bad("input_dim must be a positive multiple of 4");
+    if (cfg->num_blocks < 1) return bad("num_blocks must be >= 1");
+    if (cfg->beam_size < 1 || cfg->beam_size > ASR_MAX_BEAM) return bad("beam_size must be in 1..32");
+    if (cfg->dst_vocab_size < cfg->beam_size || cfg->dst_vocab_size < 4 || (size_t)cfg->dst_vocab_size * 4 > 150 * 1024)
+        return bad("dst_vocab_size must be in [max(4, beam_size), 38400]");
+    if (cfg->max_target_length < 1 || cfg->max_target_length > 4000) return bad("max_target_length must be in 1..4000");
+    if (cfg->ff_activation < ASR_FF_RELU || cfg->ff_activation > ASR_FF_SWISH) return bad("unknown ff_activation");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device visible (libasr_amd needs an MI355X)"; return ASR_ERR_HIP; }
+    if (cfg->device < 0 || cfg->device >= ndev) return bad("device ordinal out of range");
+
+    asr_handle* h = new asr_handle();
+    h->cfg = *cfg;
+    h->H = cfg->hidden_units; h->heads = cfg->num_heads; h->L = cfg->num_blocks; h->V = cfg->dst_vocab_size;
+    h->D = cfg->input_dim; h->F = 4 * cfg->hidden_units; h->K = cfg->beam_size;
+    h->glu = cfg->ff_activation == ASR_FF_GLU;
+    switch (cfg->ff_activation) {
+        case ASR_FF_SIGMOID: h->ff_epi = EPI_SIGMOID; break;
+        case ASR_FF_TANH: h->ff_epi = EPI_TANH; break;
+        case ASR_FF_SWISH: h->ff_epi = EPI_SWISH; break;
+        default: h->ff_epi = EPI_RELU; break;
+    }
+    auto hip_fail = [&](hipError_t e, const char* what) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+        asr_destroy(h);
+        return (int)ASR_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    if ((e = hipEventCreate(&h->pe0)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&h->pe1)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    h->step_events.resize(8);
+    for (auto& ev : h->step_events)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->done_host), (size_t)(cfg->max_target_length + 8) * sizeof(int32_t), 0)) != hipSuccess)
+        return hip_fail(e, "hipHostMalloc");
+    h->cross_kT.assign(h->L, nullptr); h->cross_v.assign(h->L, nullptr);
+    h->kcache.assign(h->L, nullptr); h->vcache.assign(h->L, nullptr);
+    *out = h;
+    return ASR_OK;
+}
+
+void asr_destroy(asr_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& kv : h->allocs) (void)hipFree(kv.first);
+    if (h->done_host) (void)hipHostFree(h->done_host);
+    for (auto ev : h->step_events) if (ev) (void)hipEventDestroy(ev);
+    if (h->pe0) (void)hipEventDestroy(h->pe0);
+    if (h->pe1) (void)hipEventDestroy(h->pe1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* asr_last_error(const asr_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int asr_load_tensor(asr_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim)
+{
+    if (!h || !name || !data || !shape || ndim < 0 || ndim > 4) return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    if (h->finalized) return fail(h, ASR_ERR_STATE, "weights already finalized");
+    const std::string n(name);
+    if (is_ignored_var(n)) return ASR_OK;
+    for (const VarSpec& v : required_vars(h)) {
+        if (v.name != n) continue;
+        std::vector<int64_t> s(shape, shape + ndim);
+        if (s != v.shape) {
+            std::string m = "shape mismatch for " + n + ": got [";
+            for (auto x : s) m += std::to_string(x) + ",";
+            m += "] want [";
+            for (auto x : v.shape) m += std::to_string(x) + ",";
+            return fail(h, ASR_ERR_WEIGHTS, m + "]");
+        }
+        size_t cnt = 1;
+        for (auto x : s) cnt *= (size_t)x;
+        HostTensor t;
+        t.shape = s;
+        t.data.assign(data, data + cnt);
+        h->staged[n] = std::move(t);
+        return ASR_OK;
+    }
+    return fail(h, ASR_ERR_WEIGHTS, "variable not in the inference graph: " + n);
+}
+
+int asr_finalize_weights(asr_handle* h)
+{
+    if (!h) return ASR_ERR_ARG;
+    if (h->finalized) return ASR_OK;
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::string missing;
+    int nmiss = 0;
+    for (const VarSpec& v : required_vars(h))
+        if (!h->staged.count(v.name)) { if (nmiss++ < 12) missing += "\n  " + v.name; }
+    if (nmiss) return fail(h, ASR_ERR_WEIGHTS, std::to_string(nmiss) + " variable(s) missing:" + missing + (nmiss > 12 ? "\n  ..." : ""));
+    if ((rc = upload(h, "encoder/src_change/kernel", &h->w_src))) return rc;
+    if ((rc = upload(h, "encoder/src_change/bias", &h->b_src))) return rc;
+    if ((rc = upload(h, "encoder/LayerNorm/gamma", &h->in_gamma))) return rc;
+    if ((rc = upload(h, "encoder/LayerNorm/beta", &h->in_beta))) return rc;
+    if ((rc = upload(h, "decoder/dst_embedding/kernel", &h->emb))) return rc;
+    if (!h->cfg.tie_embedding_and_softmax && (rc = upload(h, "decoder/softmax/kernel", &h->softmax_w))) return rc;
+    h->enc.resize(h->L);
+    h->dec.resize(h->L);
+    for (int i = 0; i < h->L; ++i) {
+        const std::string p = "encoder/block_" + std::to_string(i);
+        EncBlock& b = h->enc[i];
+        if ((rc = upload(h, p + "/encoder_self_attention/qkv_transform/kernel", &b.wqkv))) return rc;
+        if ((rc = upload(h, p + "/encoder_self_attention/qkv_transform/bias", &b.bqkv))) return rc;
+        if ((rc = upload(h, p + "/encoder_self_attention/output_transform/kernel", &b.wo))) return rc;
+        if ((rc = upload(h, p + "/encoder_self_attention/output_transform/bias", &b.bo))) return rc;
+        if ((rc = upload(h, p + "/layer_norm/layer_norm_scale", &b.ln0s))) return rc;
+        if ((rc = upload(h, p + "/layer_norm/layer_norm_bias", &b.ln0b))) return rc;
+        if ((rc = upload_ffn1(h, p, &b.w1, &b.b1))) return rc;
+        if ((rc = upload(h, p + "/ff_hidden/dense_1/kernel", &b.w2))) return rc;
+        if ((rc = upload(h, p + "/ff_hidden/dense_1/bias", &b.b2))) return rc;
+        if ((rc = upload(h, p + "/layer_norm_1/layer_norm_scale", &b.ln1s))) return rc;
+        if ((rc = upload(h, p + "/layer_norm_1/layer_norm_bias", &b.ln1b))) return rc;
+    }
+    for (int i = 0; i < h->L; ++i) {
+        const std::string p = "decoder/block_" + std::to_string(i);
+        DecBlock& b = h->dec[i];
+        if ((rc = upload(h, p + "/decoder_self_attention/qkv_transform/kernel", &b.wqkv))) return rc;
+        if ((rc = upload(h, p + "/decoder_self_attention/qkv_transform/bias", &b.bqkv))) return rc;
+        if ((rc = upload(h, p + "/decoder_self_attention/output_transform/kernel", &b.wo))) return rc;
+        if ((rc = upload(h, p + "/decoder_self_attention/output_transform/bias", &b.bo))) return rc;
+        if ((rc = upload(h, p + "/layer_norm/layer_norm_scale", &b.ln0s))) return rc;
+        if ((rc = upload(h, p + "/layer_norm/layer_norm_bias", &b.ln0b))) return rc;
+        if ((rc = upload(h, p + "/decoder_vanilla_attention/q_transform/kernel", &b.wq))) return rc;
+        if ((rc = upload(h, p + "/decoder_vanilla_attention/q_transform/bias", &b.bq))) return rc;
+        if ((rc = upload(h, p + "/decoder_vanilla_attention/kv_transform/kernel", &b.wkv))) return rc;
+        if ((rc = upload(h, p + "/decoder_vanilla_attention/kv_transform/bias", &b.bkv))) return rc;
+        if ((rc = upload(h, p + "/decoder_vanilla_attention/output_transform/kernel", &b.wco))) return rc;
+        if ((rc = upload(h, p + "/decoder_vanilla_attention/output_transform/bias", &b.bco))) return rc;
+        if ((rc = upload(h, p + "/layer_norm_1/layer_norm_scale", &b.ln1s))) return rc;
+        if ((rc = upload(h, p + "/layer_norm_1/layer_norm_bias", &b.ln1b))) return rc;
+        if ((rc = upload_ffn1(h, p, &b.w1, &b.b1))) return rc;
+        if ((rc = upload(h, p + "/ff_hidden/dense_1/kernel", &b.w2))) return rc;
+        if ((rc = upload(h, p + "/ff_hidden/dense_1/bias", &b.b2))) return rc;
+        if ((rc = upload(h, p + "/layer_norm_2/layer_norm_scale", &b.ln2s))) return rc;
+        if ((rc = upload(h, p + "/layer_norm_2/layer_norm_bias", &b.ln2b))) return rc;
+    }
+    h->staged.clear();
+    if ((rc = ensure_pe(h, h->cfg.max_target_length + 2))) return rc;
+    h->finalized = true;
+    return ASR_OK;
+}
+
+int asr_decode_dev(asr_handle* h, const float* X_dev, int32_t n, int32_t t, int32_t d, int32_t raw_frames, int32_t raw_dim,
+                   int32_t left, int32_t right, int32_t sub, int32_t* Y, int64_t y_capacity, int32_t* len_out)
+{
+    if (!h || !len_out || (n > 0 && (!X_dev || !Y))) return h ? fail(h, ASR_ERR_ARG, "null argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (raw_frames > 0) {
+        if (sub < 1 || left < 0 || right < 0 || raw_dim < 1) return fail(h, ASR_ERR_ARG, "bad frame-stacking parameters");
+        t = (raw_frames + sub - 1) / sub;
+        d = raw_dim * (left + right + 1);
+    }
+    if ((rc = check_xshape(h, n, t, d))) return rc;
+    if (n == 0) { *len_out = 0; return ASR_OK; }
+    if ((rc = ensure_encoder_capacity(h, n, t))) return rc;
+    const float* X = X_dev;
+    if (raw_frames > 0) {
+        ProfScope ps(h, "frame_stack", 0, 4.0 * n * ((double)raw_frames * raw_dim + (double)t * d));
+        HIP_TRY(h, launch_frame_stack(X_dev, n, raw_frames, raw_dim, left, right, sub, h->xin, h->stream));
+        X = h->xin;
+    }
+    return decode_core(h, X, n, t, Y, y_capacity, len_out, nullptr);
+}
+
+int asr_decode_trace(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, int32_t* Y, int64_t y_capacity,
+                     int32_t* len_out, int32_t trace_steps, float* logits, float* scores, int32_t* tokens, int32_t* parents)
+{
+    if (!h || !len_out || (n > 0 && (!X || !Y))) return h ? fail(h, ASR_ERR_ARG, "null argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = check_xshape(h, n, t, d))) return rc;
+    if (n == 0) { *len_out = 0; return ASR_OK; }
+    if ((rc = ensure_encoder_capacity(h, n, t))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->xin, X, (size_t)n * t * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    TraceOut tr;
+    tr.steps = trace_steps; tr.logits = logits; tr.scores = scores; tr.tokens = tokens; tr.parents = parents;
+    return decode_core(h, h->xin, n, t, Y, y_capacity, len_out, trace_steps > 0 ? &tr : nullptr);
+}
+
+int asr_decode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, int32_t* Y, int64_t y_capacity, int32_t* len_out)
+{
+    return asr_decode_trace(h, X, n, t, d, Y, y_capacity, len_out, 0, nullptr, nullptr, nullptr, nullptr);
+}
+
+int asr_stack_frames(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, int32_t left, int32_t right, int32_t sub,
+                     float* out)
+{
+    if (!h || !feats || !out || n_frames < 1 || dim < 1 || left < 0 || right < 0 || sub < 1)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    const int t = (n_frames + sub - 1) / sub, w = dim * (left + right + 1);
+    float *din = nullptr, *dout = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&din), (size_t)n_frames * dim * 4));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dout), (size_t)t * w * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(din, feats, (size_t)n_frames * dim * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = launch_frame_stack(din, 1, n_frames, dim, left, right, sub, dout, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)t * w * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    HIP_TRY(h, e);
+    return ASR_OK;
+}
+
+int asr_encode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, float* enc_out, int32_t* pad_out)
+{
+    if (!h || !X || !enc_out) return h ? fail(h, ASR_ERR_ARG, "null argument") : ASR_ERR_ARG;
+    if (!h->finalized) return fail(h, ASR_ERR_STATE, "asr_finalize_weights has not succeeded on this handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = check_xshape(h, n, t, d))) return rc;
+    if (n == 0) return ASR_OK;
+    if ((rc = ensure_encoder_capacity(h, n, t))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->xin, X, (size_t)n * t * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if ((rc = run_encoder(h, h->xin, n, t))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(enc_out, h->x0, (size_t)n * t * h->H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (pad_out) HIP_TRY(h, hipMemcpyAsync(pad_out, h->pad, (size_t)n * t * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ASR_OK;
+}
+
+// ---- single-kernel probes ----------------------------------------------------------------------
+
+int asr_op_dense(asr_handle* h, const float* x, const float* w, const float* bias, int32_t m, int32_t n, int32_t k, int32_t split_k,
+                 float* y)
+{
+    if (!h || !x || !w || !y || m < 1 || n < 1 || k < 4 || (k & 3) || split_k < 1 || split_k > ASR_MAX_SPLITK)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    TmpBufs tb;
+    float *dx, *dw, *db = nullptr, *dy, *dpart = nullptr;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, tb.up(&dx, x, (size_t)m * k, s));
+    HIP_TRY(h, tb.up(&dw, w, (size_t)n * k, s));
+    if (bias) HIP_TRY(h, tb.up(&db, bias, (size_t)n, s));
+    HIP_TRY(h, tb.up<float>(&dy, nullptr, (size_t)m * n, s));
+    if (split_k == 1) {
+        if ((rc = gemm(h, dx, dw, db, dy, m, n, k, EPI_BIAS, 1))) return rc;
+    } else {
+        // split-K slabs, reduced in slab order by a trivial host loop (the product path reduces them inside
+        // the consumer kernels; see asr_op_add_layer_norm for that path)
+        HIP_TRY(h, tb.up<float>(&dpart, nullptr, (size_t)split_k * m * n, s));
+        if ((rc = gemm(h, dx, dw, nullptr, dpart, m, n, k, EPI_PARTIAL, split_k))) return rc;
+        std::vector<float> part((size_t)split_k * m * n);
+        HIP_TRY(h, hipMemcpyAsync(part.data(), dpart, part.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        for (size_t i = 0; i < (size_t)m * n; ++i) {
+            float acc = 0.f;
+            for (int z = 0; z < split_k; ++z) acc += part[(size_t)z * m * n + i];
+            y[i] = acc + (bias ? bias[i % n] : 0.f);
+        }
+        return ASR_OK;
+    }
+    HIP_TRY(h, hipMemcpyAsync(y, dy, (size_t)m * n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
+int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int32_t m,
+                     int32_t n, int32_t k, float* y)
+{
+    if (!h || !x || !w1 || !w2 || !y || m < 1 || n < 32 || (n & 31) || k < 4 || (k & 3))
+        return h ? fail(h, ASR_ERR_ARG, "bad argument (n must be a multiple of 32)") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    std::vector<float> wp((size_t)2 * n * k), bp((size_t)2 * n, 0.f);
+    for (int g = 0; g < n / 32; ++g)
+        for (int r = 0; r < 32; ++r) {
+            memcpy(&wp[((size_t)g * 64 + r) * k], &w1[((size_t)g * 32 + r) * k], (size_t)k * 4);
+            memcpy(&wp[((size_t)g * 64 + 32 + r) * k], &w2[((size_t)g * 32 + r) * k], (size_t)k * 4);
+            if (b1) bp[(size_t)g * 64 + r] = b1[(size_t)g * 32 + r];
+            if (b2) bp[(size_t)g * 64 + 32 + r] = b2[(size_t)g * 32 + r];
+        }
+    TmpBufs tb;
+    float *dx, *dw, *db, *dy;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, tb.up(&dx, x, (size_t)m * k, s));
+    HIP_TRY(h, tb.up(&dw, wp.data(), wp.size(), s));
+    HIP_TRY(h, tb.up(&db, bp.data(), bp.size(), s));
+    HIP_TRY(h, tb.up<float>(&dy, nullptr, (size_t)m * n, s));
+    if ((rc = gemm(h, dx, dw, db, dy, m, 2 * n, k, EPI_GLU, 1))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(y, dy, (size_t)m * n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
+int asr_op_add_layer_norm(asr_handle* h, const float* x, const float* delta, const float* dbias, const float* scale, const float* bias,
+                          int32_t rows, int32_t hidden, float* y)
+{
+    if (!h || !x || !delta || !scale || !bias || !y || rows < 1 || hidden < 4 || (hidden & 3) || hidden > 2048)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    TmpBufs tb;
+    float *dx, *dd, *db = nullptr, *ds, *dbi, *dy;
+    hipStream_t s = h->stream;
+    const size_t cnt = (size_t)rows * hidden;
+    HIP_TRY(h, tb.up(&dx, x, cnt, s));
+    HIP_TRY(h, tb.up(&dd, delta, cnt, s));
+    if (dbias) HIP_TRY(h, tb.up(&db, dbias, (size_t)hidden, s));
+    HIP_TRY(h, tb.up(&ds, scale, (size_t)hidden, s));
+    HIP_TRY(h, tb.up(&dbi, bias, (size_t)hidden, s));
+    HIP_TRY(h, tb.up<float>(&dy, nullptr, cnt, s));
+    HIP_TRY(h, launch_add_layer_norm(dx, dd, 1, 0, db, ds, dbi, nullptr, nullptr, rows, hidden, dy, s));
+    HIP_TRY(h, hipMemcpyAsync(y, dy, cnt * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
+int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, const float* beta, int32_t n, int32_t t, int32_t hidden,
+                             float* y)
+{
+    if (!h || !x || !gamma || !beta || !y || n < 1 || t < 1 || hidden != h->H)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument (hidden must equal the handle's hidden_units)") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = ensure_pe(h, t))) return rc;
+    TmpBufs tb;
+    float *dx, *dg, *db, *dy;
+    double* dscr;
+    hipStream_t s = h->stream;
+    const size_t cnt = (size_t)n * t * hidden;
+    HIP_TRY(h, tb.up(&dx, x, cnt, s));
+    HIP_TRY(h, tb.up(&dg, gamma, (size_t)hidden, s));
+    HIP_TRY(h, tb.up(&db, beta, (size_t)hidden, s));
+    HIP_TRY(h, tb.up<float>(&dy, nullptr, cnt, s));
+    HIP_TRY(h, tb.up<double>(&dscr, nullptr, input_norm_scratch_doubles(n, t, hidden), s));
+    HIP_TRY(h, launch_input_norm_timing(dx, dg, db, h->pe, n, t, hidden, dscr, dy, s));
+    HIP_TRY(h, hipMemcpyAsync(y, dy, cnt * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
+int asr_op_encoder_attention(asr_handle* h, const float* qkv, const int32_t* pad, int32_t n, int32_t t, float* ctx)
+{
+    if (!h || !qkv || !pad || !ctx || n < 1 || t < 1) return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    TmpBufs tb;
+    float *dq, *dc;
+    int32_t* dp;
+    hipStream_t s = h->stream;
+    const size_t rows = (size_t)n * t;
+    HIP_TRY(h, tb.up(&dq, qkv, rows * 3 * h->H, s));
+    HIP_TRY(h, tb.up(&dp, pad, rows, s));
+    HIP_TRY(h, tb.up<float>(&dc, nullptr, rows * h->H, s));
+    HIP_TRY(h, launch_encoder_attention(dq, dp, n, t, h->heads, dc, s));
+    HIP_TRY(h, hipMemcpyAsync(ctx, dc, rows * h->H * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
+int asr_op_log_softmax_topk(asr_handle* h, const float* logits, int32_t rows, int32_t vocab, int32_t k, float* values, int32_t* indices)
+{
+    if (!h || !logits || !values || !indices || rows < 1 || vocab < 1 || k < 1 || k > vocab || k > ASR_MAX_BEAM)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    TmpBufs tb;
+    float *dl, *dv;
+    int32_t* di;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, tb.up(&dl, logits, (size_t)rows * vocab, s));
+    HIP_TRY(h, tb.up<float>(&dv, nullptr, (size_t)rows * k, s));
+    HIP_TRY(h, tb.up<int32_t>(&di, nullptr, (size_t)rows * k, s));
+    HIP_TRY(h, launch_log_softmax_topk(dl, rows, vocab, k, dv, di, nullptr, s));
+    HIP_TRY(h, hipMemcpyAsync(values, dv, (size_t)rows * k * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(indices, di, (size_t)rows * k * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
+int asr_op_beam_step(asr_handle* h, const float* scores, const int32_t* finished, const float* cand_scores, const int32_t* cand_tokens,
+                     int32_t b, int32_t k, float* new_scores, int32_t* tokens, int32_t* parents, int32_t* finished_out)
+{
+    if (!h || !scores || !finished || !cand_scores || !cand_tokens || !new_scores || !tokens || !parents || !finished_out || b < 1 ||
+        k < 1 || k > ASR_MAX_BEAM)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    TmpBufs tb;
+    float *ds, *dcs, *dns;
+    int32_t *df, *dct, *dt, *dp, *dfo;
+    hipStream_t s = h->stream;
+    const size_t R = (size_t)b * k;
+    HIP_TRY(h, tb.up(&ds, scores, R, s));
+    HIP_TRY(h, tb.up(&df, finished, R, s));
+    HIP_TRY(h, tb.up(&dcs, cand_scores, R * k, s));
+    HIP_TRY(h, tb.up(&dct, cand_tokens, R * k, s));
+    HIP_TRY(h, tb.up<float>(&dns, nullptr, R, s));
+    HIP_TRY(h, tb.up<int32_t>(&dt, nullptr, R, s));
+    HIP_TRY(h, tb.up<int32_t>(&dp, nullptr, R, s));
+    HIP_TRY(h, tb.up<int32_t>(&dfo, nullptr, R, s));
+    HIP_TRY(h, launch_beam_prune(ds, df, dcs, dct, b, k, dns, dt, dp, dfo, s));
+    HIP_TRY(h, hipMemcpyAsync(new_scores, dns, R * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(tokens, dt, R * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(parents, dp, R * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(finished_out, dfo, R * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
+// ---- instrumentation ---------------------------------------------------------------------------
+int asr_set_profile(asr_handle* h, int32_t mode)
+{
+    if (!h) return ASR_ERR_ARG;
+    h->profile = mode ? 1 : 0;
+    if (mode) h->prof.clear();
+    return ASR_OK;
+}
+
+int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, int64_t* launches, double* flops, double* bytes,
+                    int32_t* n_out)
+{
+    if (!h || !n_out) return ASR_ERR_ARG;
+    const int n = std::min<int>(cap, (int)h->prof.size());
+    for (int i = 0; i < n; ++i) {
+        if (names) names[i] = h->prof[i].name;
+        if (ms) ms[i] = h->prof[i].ms;
+        if (launches) launches[i] = h->prof[i].launches;
+        if (flops) flops[i] = h->prof[i].flops;
+        if (bytes) bytes[i] = h->prof[i].bytes;
+    }
+    *n_out = n;
+    return ASR_OK;
+}
+
+int64_t asr_device_bytes(const asr_handle* h) { return h ? h->dev_bytes : 0; }
+
+}  // extern "C"

@@ -1,0 +1,516 @@
+// Memory-bound row kernels of the inference path (wave64 reductions, 16-byte accesses):
+// frame stacking, padding mask, input layer norm + timing signal, residual add + layer norm,
+// embedding lookup, cross-K/V packing, fused log-softmax + top-k, and the beam pruning step.
+// Reference citations are relative to /root/reference/transformer/.
+#include "asr_common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- frame stacking: third_party/feat_convert/io/fea.py:142-149 + every `sub`-th frame ----------
+// raw [n][raw_frames][dim] -> out [n][t][dim*(left+right+1)], t = ceil(raw_frames/sub);
+// context frames outside [0, len_u) read as zero; stacked frames t >= ceil(len_u/sub) are zero rows.
+__global__ void frame_stack_kernel(const float* __restrict__ raw, const int32_t* __restrict__ lens, int raw_frames,
+                                   int dim, int left, int right, int sub, int t, float* __restrict__ out)
+{
+    const int u = blockIdx.y, tt = blockIdx.x;
+    const int len = lens ? lens[u] : raw_frames;
+    const int tlen = (len + sub - 1) / sub;
+    const int width = dim * (left + right + 1);
+    float* o = out + ((size_t)u * t + tt) * width;
+    const float* r = raw + (size_t)u * raw_frames * dim;
+    for (int c = threadIdx.x; c < width; c += blockDim.x) {
+        const int ctx = c / dim, d = c - ctx * dim;
+        const int f = tt * sub + ctx - left;
+        float v = 0.f;
+        if (tt < tlen && f >= 0 && f < len) v = r[(size_t)f * dim + d];
+        o[c] = v;
+    }
+}
+
+// ---- encoder_padding = (sum_d |X| == 0)  (model.py:450) -----------------------------------------
+__global__ void pad_mask_kernel(const float* __restrict__ X, int rows, int d, int32_t* __restrict__ pad)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = X + (size_t)row * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += fabsf(x[c]);
+    s = wave_sum(s);
+    if (lane == 0) pad[row] = (s == 0.0f) ? 1 : 0;
+}
+
+// ---- tf.contrib.layers.layer_norm over (t, hidden) + timing signal (model.py:453,456; Q1) -------
+constexpr int IN_CHUNKS = 64;     // partial sums per utterance
+
+template <int PASS>   // 0: sum x    1: sum (x - mean)^2
+__global__ __launch_bounds__(256) void input_norm_stats_kernel(const float* __restrict__ x, size_t per_utt,
+                                                                double* __restrict__ scratch)
+{
+    // scratch layout per utterance u: [0..63] sums, [64..127] squared-deviation sums
+    const int u = blockIdx.y, c = blockIdx.x;
+    double* su = scratch + (size_t)u * (2 * IN_CHUNKS);
+    float mean = 0.f;
+    if (PASS == 1) {
+        double tot = 0.0;
+        for (int i = 0; i < IN_CHUNKS; ++i) tot += su[i];
+        mean = (float)(tot / (double)per_utt);
+    }
+    const size_t n4 = per_utt / 4;
+    const size_t per_chunk = (n4 + IN_CHUNKS - 1) / IN_CHUNKS;
+    const size_t beg = (size_t)c * per_chunk, end = min(n4, beg + per_chunk);
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + (size_t)u * per_utt);
+    float acc = 0.f;
+    for (size_t i = beg + threadIdx.x; i < end; i += 256) {
+        f32x4 v = xp[i];
+        if (PASS == 0) acc += (v[0] + v[1]) + (v[2] + v[3]);
+        else {
+            const float a = v[0] - mean, b = v[1] - mean, cc = v[2] - mean, d = v[3] - mean;
+            acc += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    __shared__ double red[4];
+    double dsum = wave_sum_d((double)acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) su[PASS * IN_CHUNKS + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void input_norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ pe,
+                                                                int t, int hidden, const double* __restrict__ scratch,
+                                                                float* __restrict__ y)
+{
+    const int u = blockIdx.y;
+    const size_t per_utt = (size_t)t * hidden;
+    const double* su = scratch + (size_t)u * (2 * IN_CHUNKS);
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = 0; i < IN_CHUNKS; ++i) { s0 += su[i]; s1 += su[IN_CHUNKS + i]; }
+    const float mean = (float)(s0 / (double)per_utt);
+    const float var = (float)(s1 / (double)per_utt);
+    const float rstd = 1.0f / sqrtf(var + 1e-12f);
+    const int h4 = hidden / 4;
+    const size_t n4 = per_utt / 4;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + (size_t)u * per_utt);
+    f32x4* yp = reinterpret_cast<f32x4*>(y + (size_t)u * per_utt);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+    const f32x4* pe4 = reinterpret_cast<const f32x4*>(pe);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int hc = (int)(i % h4);
+        const f32x4 v = xp[i], g = g4[hc], b = b4[hc], p = pe4[i];   // pe is [t][hidden], same linear index
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float inv = rstd * g[j];               // tf.nn.batch_normalization: x*inv + (beta - mean*inv)
+            o[j] = (v[j] * inv + (b[j] - mean * inv)) + p[j];
+        }
+        yp[i] = o;
+    }
+}
+
+// ---- utils.residual: layer_norm(x + y), eps 1e-6 (utils.py:494-507; common_layers.py:333-338) ---
+// One wave per row.  Input row = resid + dbias + sum_z part[z] (split-K slabs reduced here, in z
+// order, so the projection GEMM needs no reduction pass of its own).
+template <int NCH>   // 16-byte chunks per lane: hidden <= NCH*256
+__global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* __restrict__ resid, const float* __restrict__ part,
+                                                              int nsplit, size_t split_stride, const float* __restrict__ dbias,
+                                                              const float* __restrict__ scale, const float* __restrict__ bias,
+                                                              const int32_t* __restrict__ mask, int32_t* __restrict__ pad2_out,
+                                                              int rows, int hidden, float* __restrict__ y,
+                                                              const int32_t* __restrict__ done)
+{
+    if (done && *done) return;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int h4 = hidden >> 2;
+    const size_t base = (size_t)row * hidden;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (ch < h4) {
+            a = reinterpret_cast<const f32x4*>(resid + base)[ch];
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < nsplit; ++z) d += reinterpret_cast<const f32x4*>(part + z * split_stride + base)[ch];
+            if (dbias) d += reinterpret_cast<const f32x4*>(dbias)[ch];
+            a += d;                                         // inputs + outputs (utils.py:505)
+            s += (a[0] + a[1]) + (a[2] + a[3]);
+        }
+        v[c] = a;
+    }
+    const float mean = wave_sum(s) / (float)hidden;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (lane + 64 * c < h4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float dlt = v[c][j] - mean; q += dlt * dlt; }
+        }
+    }
+    const float var = wave_sum(q) / (float)hidden;
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    const bool zero_row = mask && mask[row];
+    float asum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < h4) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(scale)[ch], b = reinterpret_cast<const f32x4*>(bias)[ch];
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = ((v[c][j] - mean) * rstd) * g[j] + b[j];
+                if (zero_row) o[j] = o[j] * 0.0f;            // encoder_output *= (1 - padding) (model.py:489)
+                asum += fabsf(o[j]);
+            }
+            reinterpret_cast<f32x4*>(y + base)[ch] = o;
+        }
+    }
+    if (pad2_out) {                                          // decoder re-detects padding (model.py:566)
+        asum = wave_sum(asum);
+        if (lane == 0) pad2_out[row] = (asum == 0.0f) ? 1 : 0;
+    }
+}
+
+// ---- embedding * sqrt(H) + timing signal of the current position (model.py:569-576) ------------
+__global__ __launch_bounds__(256) void embed_pe_kernel(const float* __restrict__ E, const int32_t* __restrict__ preds0,
+                                                        const int32_t* __restrict__ preds1, int preds_stride,
+                                                        const int32_t* __restrict__ pos_dev, const float* __restrict__ pe,
+                                                        float mult, int hidden, float* __restrict__ y,
+                                                        const int32_t* __restrict__ done)
+{
+    if (*done) return;
+    const int r = blockIdx.x;
+    const int pos = *pos_dev;
+    const int32_t* preds = (pos & 1) ? preds1 : preds0;
+    const int tok = preds[(size_t)r * preds_stride + pos];
+    const f32x4* e = reinterpret_cast<const f32x4*>(E + (size_t)tok * hidden);
+    const f32x4* p = reinterpret_cast<const f32x4*>(pe + (size_t)pos * hidden);
+    f32x4* o = reinterpret_cast<f32x4*>(y + (size_t)r * hidden);
+    for (int c = threadIdx.x; c < hidden / 4; c += 256) {
+        f32x4 v = e[c];
+        if (mult != 1.0f) v = v * mult;
+        o[c] = v + p[c];
+    }
+}
+
+// ---- cross-attention K/V layouts: kv [n*t][2H] -> kT [n][heads][64][tp], v [n][heads][t][64] ----
+__global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restrict__ kv, int t, int tp, int heads,
+                                                             float* __restrict__ kT, float* __restrict__ vout)
+{
+    __shared__ float tile[64][65];
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, u = blockIdx.z;
+    const int hidden = heads * 64;
+    const int tid = threadIdx.x;
+    // load K tile [64 t][64 d] (coalesced over d) and copy V
+    for (int i = tid; i < 64 * 16; i += 256) {
+        const int tt = i >> 4, c = i & 15;
+        f32x4 k4 = {0.f, 0.f, 0.f, 0.f};
+        if (t0 + tt < t) {
+            const float* row = kv + ((size_t)u * t + t0 + tt) * (2 * hidden);
+            k4 = reinterpret_cast<const f32x4*>(row + h * 64)[c];
+            const f32x4 v4 = reinterpret_cast<const f32x4*>(row + hidden + h * 64)[c];
+            reinterpret_cast<f32x4*>(vout + (((size_t)u * heads + h) * t + t0 + tt) * 64)[c] = v4;
+        }
+        tile[tt][c * 4 + 0] = k4[0]; tile[tt][c * 4 + 1] = k4[1]; tile[tt][c * 4 + 2] = k4[2]; tile[tt][c * 4 + 3] = k4[3];
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int d = i >> 6, tt = i & 63;
+        if (t0 + tt < tp) kT[(((size_t)u * heads + h) * 64 + d) * tp + t0 + tt] = tile[tt][d];
+    }
+}
+
+// ---- model.test_output: log_softmax + top_k (model.py:345-347) -----------------------------------
+// One workgroup per row; the row lives in LDS (vocab*4 bytes).  Candidate order: value descending,
+// ties -> lower index (Q5).  z = (x - max) - log(sum exp(x - max)) exactly as tf.nn.log_softmax.
+__global__ __launch_bounds__(256) void log_softmax_topk_kernel(const float* __restrict__ logits, int vocab, int k,
+                                                                float* __restrict__ values, int32_t* __restrict__ indices,
+                                                                const int32_t* __restrict__ done)
+{
+    if (done && *done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* z = reinterpret_cast<float*>(smem_raw);
+    __shared__ float redv[4];
+    __shared__ int redi[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (size_t)r * vocab;
+    float m = -INFINITY;
+    for (int i = tid; i < vocab; i += 256) { const float v = x[i]; z[i] = v; m = fmaxf(m, v); }
+    m = wave_max(m);
+    if (lane == 0) redv[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < vocab; i += 256) { const float sh = z[i] - m; z[i] = sh; s += expf(sh); }
+    s = wave_sum(s);
+    if (lane == 0) redv[wave] = s;
+    __syncthreads();
+    const float logz = logf((redv[0] + redv[1]) + (redv[2] + redv[3]));
+    __syncthreads();
+    for (int i = tid; i < vocab; i += 256) z[i] = z[i] - logz;
+    __syncthreads();
+    for (int round = 0; round < k; ++round) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = tid; i < vocab; i += 256) { const float v = z[i]; if (v > bv) { bv = v; bi = i; } }   // i ascending: first max kept
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
+            values[(size_t)r * k + round] = bv;
+            indices[(size_t)r * k + round] = bi;
+            if (bi < vocab) z[bi] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- beam pruning (model.py:280-301) ------------------------------------------------
+// One workgroup per utterance.  K*K candidates are ranked by counting (value desc, ties -> lower
+// flat index), which reproduces a sorted tf.nn.top_k.
+struct BeamLds {
+    float tot[ASR_MAX_BEAM * ASR_MAX_BEAM];
+    int ctok[ASR_MAX_BEAM * ASR_MAX_BEAM];
+    float nscore[ASR_MAX_BEAM];
+    int ntok[ASR_MAX_BEAM];
+    int npar[ASR_MAX_BEAM];      // parent beam, local to the utterance
+};
+
+__device__ void beam_prune_block(const float* scores, const int32_t* finished, const float* cand_scores,
+                                 const int32_t* cand_tokens, int k, int u, BeamLds& L)
+{
+    const int kk = k * k, tid = threadIdx.x, nth = blockDim.x;
+    for (int c = tid; c < kk; c += nth) {
+        const int beam = c / k, j = c - beam * k;
+        const int r = u * k + beam;
+        const bool f = finished[r] != 0;
+        // scores*(1-f) + b*f with b = [0, -1e10, ...]  (model.py:238-240); tokens*(1-f) + 3*f (:253)
+        const float cs = f ? (j == 0 ? 0.0f : -1e10f) : cand_scores[(size_t)r * k + j];
+        L.ctok[c] = f ? 3 : cand_tokens[(size_t)r * k + j];
+        L.tot[c] = scores[r] + cs;
+    }
+    __syncthreads();
+    for (int c = tid; c < kk; c += nth) {
+        const float v = L.tot[c];
+        int rank = 0;
+        for (int o = 0; o < kk; ++o) { const float w = L.tot[o]; rank += (w > v || (w == v && o < c)) ? 1 : 0; }
+        if (rank < k) { L.nscore[rank] = v; L.ntok[rank] = L.ctok[c]; L.npar[rank] = c / k; }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void beam_prune_kernel(const float* scores, const int32_t* finished, const float* cand_scores,
+                                                          const int32_t* cand_tokens, int k, float* new_scores,
+                                                          int32_t* tokens, int32_t* parents, int32_t* finished_out)
+{
+    __shared__ BeamLds L;
+    const int u = blockIdx.x;
+    beam_prune_block(scores, finished, cand_scores, cand_tokens, k, u, L);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const int r = u * k + i;
+        new_scores[r] = L.nscore[i]; tokens[r] = L.ntok[i]; parents[r] = u * k + L.npar[i];
+        finished_out[r] = (L.ntok[i] == 3) ? 1 : 0;
+    }
+}
+
+__global__ void beam_init_kernel(BeamState st, int rows, int k)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) { *st.pos = 0; *st.done = 0; *st.unfinished = 0; }
+    if (r >= rows) return;
+    st.scores[0][r] = (r % k == 0) ? 0.0f : -1e10f;          // model.py:264-265
+    st.finished[0][r] = 0;                                   // :266
+    st.preds[0][(size_t)r * st.width] = 2;                   // <S>  (:263)
+}
+
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* cand_scores, const int32_t* cand_tokens, int k)
+{
+    if (*st.done) return;
+    __shared__ BeamLds L;
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const int pos = *st.pos, cur = pos & 1, nxt = cur ^ 1;
+    beam_prune_block(st.scores[cur], st.finished[cur], cand_scores, cand_tokens, k, u, L);
+    // preds = concat(gather(preds, parent), token); ancestry table gathered the same way (model.py:296-298)
+    const int w = st.width;
+    for (int i = tid; i < k * (pos + 1); i += blockDim.x) {
+        const int beam = i / (pos + 1), j = i - beam * (pos + 1);
+        const size_t dst = (size_t)(u * k + beam) * w + j, src = (size_t)(u * k + L.npar[beam]) * w + j;
+        st.preds[nxt][dst] = st.preds[cur][src];
+        st.anc[nxt][dst] = (j < pos) ? st.anc[cur][src] : L.npar[beam];   // position `pos` was computed in slot `parent`
+    }
+    if (tid < k) {
+        const int r = u * k + tid;
+        st.scores[nxt][r] = L.nscore[tid];
+        st.finished[nxt][r] = (L.ntok[tid] == 3) ? 1 : 0;                 // :301
+        st.preds[nxt][(size_t)r * w + pos + 1] = L.ntok[tid];
+        st.tokens[r] = L.ntok[tid];
+        st.parents[r] = u * k + L.npar[tid];
+    }
+    if (tid == 0) {
+        int any = 0;
+        for (int i = 0; i < k; ++i) any |= (L.ntok[i] != 3);
+        if (any) atomicAdd(st.unfinished, 1);
+    }
+}
+
+// loop condition (model.py:305-312): continue while any(!finished) and steps_done <= limit
+__global__ void beam_loop_ctl_kernel(BeamState st)
+{
+    if (*st.done) return;
+    const int pos = *st.pos + 1;
+    *st.pos = pos;
+    const int any = *st.unfinished;
+    *st.unfinished = 0;
+    if (!(any > 0 && pos <= st.limit)) *st.done = 1;
+}
+
+}  // namespace
+
+hipError_t launch_frame_stack_lens(const float* raw, const int32_t* lens, int n, int raw_frames, int raw_dim, int left,
+                                   int right, int sub, float* out, hipStream_t s)
+{
+    if (n <= 0 || raw_frames <= 0) return hipSuccess;
+    const int t = (raw_frames + sub - 1) / sub;
+    hipLaunchKernelGGL(frame_stack_kernel, dim3(t, n), dim3(128), 0, s, raw, lens, raw_frames, raw_dim, left, right, sub, t, out);
+    return hipGetLastError();
+}
+hipError_t launch_frame_stack(const float* raw, int n, int raw_frames, int raw_dim, int left, int right, int sub,
+                              float* out, hipStream_t s)
+{
+    return launch_frame_stack_lens(raw, nullptr, n, raw_frames, raw_dim, left, right, sub, out, s);
+}
+
+hipError_t launch_pad_mask(const float* X, int rows, int d, int32_t* pad, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pad_mask_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, X, rows, d, pad);
+    return hipGetLastError();
+}
+
+size_t input_norm_scratch_doubles(int n, int, int) { return (size_t)n * 2 * IN_CHUNKS; }
+
+hipError_t launch_input_norm_timing(const float* x, const float* gamma, const float* beta, const float* pe, int n, int t,
+                                    int hidden, double* scratch, float* y, hipStream_t s)
+{
+    if (n <= 0 || t <= 0) return hipSuccess;
+    if (hidden & 3) return hipErrorInvalidValue;
+    const size_t per_utt = (size_t)t * hidden;
+    hipLaunchKernelGGL(input_norm_stats_kernel<0>, dim3(IN_CHUNKS, n), dim3(256), 0, s, x, per_utt, scratch);
+    hipLaunchKernelGGL(input_norm_stats_kernel<1>, dim3(IN_CHUNKS, n), dim3(256), 0, s, x, per_utt, scratch);
+    const int gx = (int)min((size_t)64, (per_utt / 4 + 255) / 256);
+    hipLaunchKernelGGL(input_norm_apply_kernel, dim3(gx, n), dim3(256), 0, s, x, gamma, beta, pe, t, hidden, scratch, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_layer_norm_done(const float* resid, const float* part, int nsplit, size_t split_stride,
+                                      const float* dbias, const float* scale, const float* bias, const int32_t* mask,
+                                      int32_t* pad2_out, int rows, int hidden, float* y, const int32_t* done, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    if ((hidden & 3) || hidden > 2048) return hipErrorInvalidValue;
+    dim3 grid((rows + 3) / 4), block(256);
+#define ALN(N) hipLaunchKernelGGL(add_layer_norm_kernel<N>, grid, block, 0, s, resid, part, nsplit, split_stride, dbias, \
+                                  scale, bias, mask, pad2_out, rows, hidden, y, done)
+    if (hidden <= 256) ALN(1);
+    else if (hidden <= 512) ALN(2);
+    else if (hidden <= 1024) ALN(4);
+    else ALN(8);
+#undef ALN
+    return hipGetLastError();
+}
+hipError_t launch_add_layer_norm(const float* resid, const float* part, int nsplit, size_t split_stride, const float* dbias,
+                                 const float* scale, const float* bias, const int32_t* mask, int32_t* pad2_out, int rows,
+                                 int hidden, float* y, hipStream_t s)
+{
+    return launch_add_layer_norm_done(resid, part, nsplit, split_stride, dbias, scale, bias, mask, pad2_out, rows, hidden, y,
+                                      nullptr, s);
+}
+
+hipError_t launch_embed_pe(const float* E, const int32_t* preds0, const int32_t* preds1, int preds_stride,
+                           const int32_t* pos_dev, const float* pe, float mult, int rows, int hidden, float* y,
+                            const int32_t* done, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(embed_pe_kernel, dim3(rows), dim3(256), 0, s, E, preds0, preds1, preds_stride, pos_dev, pe, mult,
+                       hidden, y, done);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int tp, int heads, float* kT, float* v, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_cross_kv_kernel, dim3((tp + 63) / 64, heads, n), dim3(256), 0, s, kv, t, tp, heads, kT, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_log_softmax_topk(const float* logits, int rows, int vocab, int k, float* values, int32_t* indices,
+                                   const int32_t* done, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    const size_t lds = (size_t)vocab * sizeof(float);
+    if (lds > 150 * 1024 || k < 1 || k > vocab) return hipErrorInvalidValue;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(log_softmax_topk_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(log_softmax_topk_kernel, dim3(rows), dim3(256), lds, s, logits, vocab, k, values, indices, done);
+    return hipGetLastError();
+}
+
+hipError_t launch_beam_init(const BeamState& st, int b, int k, hipStream_t s)
+{
+    const int rows = b * k;
+    hipLaunchKernelGGL(beam_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, st, rows, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_beam_step(const BeamState& st, const float* cand_scores, const int32_t* cand_tokens, int b, int k,
+                            hipStream_t s)
+{
+    hipLaunchKernelGGL(beam_step_kernel, dim3(b), dim3(256), 0, s, st, cand_scores, cand_tokens, k);
+    hipLaunchKernelGGL(beam_loop_ctl_kernel, dim3(1), dim3(1), 0, s, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_beam_prune(const float* scores, const int32_t* finished, const float* cand_scores,
+                             const int32_t* cand_tokens, int b, int k, float* new_scores, int32_t* tokens,
+                             int32_t* parents, int32_t* finished_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(beam_prune_kernel, dim3(b), dim3(256), 0, s, scores, finished, cand_scores, cand_tokens, k,
+                       new_scores, tokens, parents, finished_out);
+    return hipGetLastError();
+}

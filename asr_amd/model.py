@@ -1,0 +1,235 @@
+"""Host-side mirror of the reference's `transformer/model.py` inference surface.
+
+`Transformer(config, num_gpus)` + `build_test_model()` + `restore(...)` + `predict(X)` stand in for
+the TF graph built by `Model.build_test_model` (model.py:162-204) and the
+`sess.run(model.prediction, feed_dict=expand_feed_dict({model.src_pls: X}))` call of
+`Evaluator.beam_search` (evaluate.py:46-47).  All arithmetic happens in libasr_amd.so (HIP, gfx950);
+this file only shards, pads and concatenates like the reference's towers do (Q10).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+from .utils import shard_bounds
+
+
+class Engine(object):
+    """One libasr_amd handle = one GPU's weights, K/V caches and workspaces."""
+
+    def __init__(self, config, device=0):
+        t = config.test
+        c = _lib.asr_config()
+        c.input_dim = int(config.train.input_dim)
+        c.hidden_units = int(config.hidden_units)
+        c.num_heads = int(config.num_heads)
+        c.num_blocks = int(config.num_blocks)
+        c.dst_vocab_size = int(config.dst_vocab_size)
+        act = config.ff_activation or 'relu'
+        if act not in _lib.FF_ACTIVATIONS:
+            raise ValueError('unknown ff_activation %r' % act)
+        c.ff_activation = _lib.FF_ACTIVATIONS[act]
+        c.scale_embedding = 1 if config.scale_embedding else 0
+        c.tie_embedding_and_softmax = 1 if config.tie_embedding_and_softmax else 0
+        c.beam_size = int(t.beam_size)
+        c.max_target_length = int(t.max_target_length)
+        c.lp_alpha = float(t.lp_alpha)
+        c.device = int(device)
+        self.cfg = c
+        self.device = int(device)
+        self._h = C.c_void_p()
+        rc = lib.asr_create(C.byref(c), C.byref(self._h))
+        _lib.check(None, rc)
+        self.hidden = c.hidden_units
+        self.vocab = c.dst_vocab_size
+        self.beam = c.beam_size
+        self.input_dim = c.input_dim
+        self.max_len = c.max_target_length + 1
+
+    def close(self):
+        if getattr(self, '_h', None):
+            lib.asr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------
+    def load_weights(self, variables):
+        """`variables`: mapping TF variable name -> array (names of SURVEY.md A.1; optimizer slots,
+        `global_step`, `beta?_power` are skipped by the library)."""
+        for name, arr in variables.items():
+            a = np.asarray(arr)
+            if a.dtype.kind not in 'fiu':
+                continue
+            if name.startswith('global_step') or a.dtype.kind in 'iu':
+                continue
+            a = _lib.f32(a)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            _lib.check(self._h, lib.asr_load_tensor(self._h, name.encode('utf-8'), _lib.fptr(a), shape, a.ndim))
+        _lib.check(self._h, lib.asr_finalize_weights(self._h))
+
+    # ---- the hot path ---------------------------------------------------------------------------
+    def decode(self, X):
+        """X float32 [n, t, input_dim] (zero rows = padding) -> int32 [n, len], padded with 3."""
+        X = _lib.f32(X)
+        n, t, d = X.shape
+        if n == 0:
+            return np.zeros((0, 0), np.int32)
+        Y = np.empty((n, self.max_len), np.int32)
+        ln = C.c_int32(0)
+        _lib.check(self._h, lib.asr_decode(self._h, _lib.fptr(X), n, t, d, _lib.iptr(Y), Y.size, C.byref(ln)))
+        return np.ascontiguousarray(Y.reshape(-1)[:n * ln.value].reshape(n, ln.value))
+
+    def decode_dev(self, ptr, n, t, d, raw=None):
+        """Device-resident input (bench): `ptr` = device address of X [n,t,d], or with
+        raw=(raw_frames, raw_dim, left, right, sub) of RAW fbank [n, raw_frames, raw_dim]."""
+        rf, rd, left, right, sub = raw if raw else (0, 0, 0, 0, 1)
+        Y = np.empty((n, self.max_len), np.int32)
+        ln = C.c_int32(0)
+        _lib.check(self._h, lib.asr_decode_dev(self._h, C.c_void_p(ptr), n, t, d, rf, rd, left, right, sub,
+                                               _lib.iptr(Y), Y.size, C.byref(ln)))
+        return np.ascontiguousarray(Y.reshape(-1)[:n * ln.value].reshape(n, ln.value))
+
+    def decode_trace(self, X, trace_steps):
+        X = _lib.f32(X)
+        n, t, d = X.shape
+        R = n * self.beam
+        Y = np.empty((n, self.max_len), np.int32)
+        ln = C.c_int32(0)
+        logits = np.zeros((trace_steps, R, self.vocab), np.float32)
+        scores = np.zeros((trace_steps, R), np.float32)
+        tokens = np.zeros((trace_steps, R), np.int32)
+        parents = np.zeros((trace_steps, R), np.int32)
+        _lib.check(self._h, lib.asr_decode_trace(self._h, _lib.fptr(X), n, t, d, _lib.iptr(Y), Y.size, C.byref(ln),
+                                                 trace_steps, _lib.fptr(logits), _lib.fptr(scores),
+                                                 _lib.iptr(tokens), _lib.iptr(parents)))
+        Y = np.ascontiguousarray(Y.reshape(-1)[:n * ln.value].reshape(n, ln.value))
+        return Y, dict(logits=logits, scores=scores, tokens=tokens, parents=parents)
+
+    def encode(self, X):
+        X = _lib.f32(X)
+        n, t, d = X.shape
+        out = np.empty((n, t, self.hidden), np.float32)
+        pad = np.empty((n, t), np.int32)
+        _lib.check(self._h, lib.asr_encode(self._h, _lib.fptr(X), n, t, d, _lib.fptr(out), _lib.iptr(pad)))
+        return out, pad
+
+    def stack_frames(self, feats, left=3, right=0, sub=3):
+        feats = _lib.f32(feats)
+        n, dim = feats.shape
+        out = np.empty(((n + sub - 1) // sub, dim * (left + right + 1)), np.float32)
+        _lib.check(self._h, lib.asr_stack_frames(self._h, _lib.fptr(feats), n, dim, left, right, sub, _lib.fptr(out)))
+        return out
+
+    # ---- instrumentation ---------------------------------------------------------------------
+    def set_profile(self, on):
+        _lib.check(self._h, lib.asr_set_profile(self._h, 1 if on else 0))
+
+    def get_profile(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        launches = (C.c_int64 * cap)()
+        flops = (C.c_double * cap)()
+        nbytes = (C.c_double * cap)()
+        n = C.c_int32(0)
+        _lib.check(self._h, lib.asr_get_profile(self._h, cap, names, ms, launches, flops, nbytes, C.byref(n)))
+        return [dict(name=names[i].decode(), ms=ms[i], launches=launches[i], flops=flops[i], bytes=nbytes[i])
+                for i in range(n.value)]
+
+    def device_bytes(self):
+        return int(lib.asr_device_bytes(self._h))
+
+
+def visible_devices():
+    return int(lib.asr_device_count())
+
+
+def default_device():
+    """Under `torch.distributed.run` each rank owns the GPU named by LOCAL_RANK."""
+    for key in ('ASR_AMD_DEVICE', 'LOCAL_RANK'):
+        if os.environ.get(key, '') != '':
+            return int(os.environ[key])
+    return 0
+
+
+class Model(object):
+    """Inference-only counterpart of model.Model (model.py:18-45,162-204).
+
+    `num_gpus` is the number of towers: the batch is split on dim 0 exactly as
+    `expand_feed_dict` does (utils.py:420-443), each shard is decoded on its own (its own padded
+    length T, Q7/Q10), predictions are padded with 3 to the longest and concatenated in tower
+    order.  Towers are placed round-robin on the GPUs visible to this process (`devices`);
+    towers on different GPUs run concurrently."""
+
+    def __init__(self, config, num_gpus, devices=None):
+        self._config = config
+        self._num_towers = max(int(num_gpus or 0), 1)            # model.py:27: 0 GPUs -> one CPU tower
+        if devices is None:
+            if 'LOCAL_RANK' in os.environ or 'ASR_AMD_DEVICE' in os.environ:
+                devices = [default_device()]
+            else:
+                devices = list(range(max(1, min(self._num_towers, visible_devices()))))
+        self._devices = list(devices)
+        self.engines = []
+        self.encoder_scope = 'encoder'
+        self.decoder_scope = 'decoder'
+
+    def build_test_model(self, reuse=None):
+        logging.info('Build test model.')
+        if not self.engines:
+            self.engines = [Engine(self._config, d) for d in self._devices]
+
+    def restore(self, variables):
+        for e in self.engines:
+            e.load_weights(variables)
+
+    def predict(self, X):
+        """== sess.run(self.prediction, expand_feed_dict({self.src_pls: X}))."""
+        X = np.asarray(X, dtype=np.float32)
+        bounds = shard_bounds(X.shape[0], self._num_towers)
+        preds = [None] * self._num_towers
+        by_engine = {}
+        for i, (a, b) in enumerate(bounds):
+            by_engine.setdefault(i % len(self.engines), []).append((i, a, b))
+
+        def work(ei, items):
+            for (i, a, b) in items:
+                preds[i] = self.engines[ei].decode(X[a:b]) if b > a else np.zeros((0, 0), np.int32)   # model.py:184-187
+
+        if len(by_engine) == 1:
+            work(*next(iter(by_engine.items())))
+        else:
+            errs = []
+
+            def guarded(ei, items):
+                try:
+                    work(ei, items)
+                except Exception as ex:      # re-raised below
+                    errs.append(ex)
+            threads = [threading.Thread(target=guarded, args=kv) for kv in by_engine.items()]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            if errs:
+                raise errs[0]
+        max_length = max(p.shape[1] for p in preds)                                                  # model.py:192
+        preds = [np.concatenate([p, np.full((p.shape[0], max_length - p.shape[1]), 3, np.int32)], axis=1)
+                 for p in preds]                                                                     # :194-200
+        return np.concatenate(preds, axis=0)                                                         # :201
+
+
+class Transformer(Model):
+    """config.model == 'Transformer' (model.py:434-442)."""
+    pass

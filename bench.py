@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decoded audio-seconds per second (RTFx) of the batched inference path
+(frame stacking -> encoder -> beam-search decoder) on BASELINE.json's config 2:
+char yaml architecture (hidden 1024, 16 heads, 6+6 blocks, GLU FFN 4096, tied V=3900), beam 10,
+max_target_length 200, 64 synthetic 10-second utterances per GPU per step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; every rank decodes its own 64-utterance batch (weak scaling, utterances are
+independent), then the hypotheses are gathered with one RCCL all_gather of a fixed-width int32
+buffer (the path's only exchange, model.py:192-201).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak
+PEAK_HBM_GBS = 8000.0            # same guide: HBM3E 8 TB/s
+
+
+def bench_config(beam=10, mtl=200):
+    from asr_amd.utils import AttrDict
+    return AttrDict({
+        'model': 'Transformer', 'dst_vocab_size': 3900, 'hidden_units': 1024, 'scale_embedding': True,
+        'tie_embedding_and_softmax': True, 'num_blocks': 6, 'num_heads': 16, 'ff_activation': 'glu',
+        'train': {'input_dim': 320},
+        'test': {'batch_size': 64, 'max_target_length': mtl, 'lp_alpha': 0.6, 'beam_size': beam, 'num_gpus': 1},
+    })
+
+
+def synthetic_raw(n, t_raw, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((n, t_raw, 80)).astype(np.float32)
+
+
+def cpu_baseline(cfg, W, raw, sample_utts):
+    """The oracle (CPU restatement of the reference algorithm, K/V-cache formulation: the variant most
+    favourable to the CPU) timed on this box's host cores over a bounded sample of the same workload."""
+    from oracle import asr_oracle as O
+    try:
+        import threadpoolctl
+        info = threadpoolctl.threadpool_info()
+        cores = max([i.get('num_threads', 1) for i in info] or [1])
+    except Exception:
+        cores = int(os.environ.get('OMP_NUM_THREADS', '1'))
+    ocfg = O.make_config(hidden_units=cfg.hidden_units, num_heads=cfg.num_heads, num_blocks=cfg.num_blocks,
+                         dst_vocab_size=cfg.dst_vocab_size, input_dim=cfg.train.input_dim,
+                         ff_activation=cfg.ff_activation, scale_embedding=cfg.scale_embedding,
+                         tie_embedding_and_softmax=cfg.tie_embedding_and_softmax, beam_size=cfg.test.beam_size,
+                         max_target_length=cfg.test.max_target_length, lp_alpha=cfg.test.lp_alpha)
+    X = O.make_batch([raw[i] for i in range(sample_utts)])
+    t0 = time.time()
+    Y = O.build_test_model(X, W, ocfg, num_gpus=1, algo='kv')
+    dt = time.time() - t0
+    audio_s = sample_utts * raw.shape[1] / 100.0
+    return {'value': audio_s / dt, 'unit': 'audio-sec/sec', 'cores': int(cores), 'kind': 'port',
+            'sample': '%d of the 64 utterances (%.0f audio-s), beam %d, %d decode steps, numpy/OpenBLAS float32, '
+                      'K/V-cache formulation of the reference algorithm; %.1f s wall'
+                      % (sample_utts, audio_s, cfg.test.beam_size, Y.shape[1], dt)}, Y
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--t-raw', type=int, default=1000)
+    ap.add_argument('--beam', type=int, default=10)
+    ap.add_argument('--max-target-length', type=int, default=200)
+    ap.add_argument('--cpu-sample-utts', type=int, default=4)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+
+    import torch
+    import torch.distributed as dist
+    from asr_amd import weights
+    from asr_amd.model import Engine
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+
+    cfg = bench_config(args.beam, args.max_target_length)
+    W = weights.random_init(cfg, seed=0)
+    eng = Engine(cfg, local_rank)
+    eng.load_weights(W)
+
+    n, t_raw = args.batch, args.t_raw
+    raw = synthetic_raw(n, t_raw, seed=1000 + rank)
+    d_raw = torch.from_numpy(raw).cuda(local_rank)
+    torch.cuda.synchronize()
+    width = args.max_target_length + 1
+    front = (t_raw, 80, 3, 0, 3)
+
+    def step():
+        Y = eng.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
+        if world > 1:      # gather the hypotheses (fixed width, padded with 3) on every rank
+            buf = torch.full((n, width), 3, dtype=torch.int32)
+            buf[:, :Y.shape[1]] = torch.from_numpy(Y)
+            buf = buf.cuda(local_rank)
+            out = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(out, buf)
+        return Y
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    Y = None
+    for _ in range(args.warmup):
+        Y = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        Y = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        audio_s = world * n * t_raw / 100.0 * args.steps
+        out = {
+            'metric': 'decoded audio-sec/sec (RTFx) whole node, char unit512 block6, beam=%d' % args.beam,
+            'value': audio_s / elapsed, 'unit': 'audio-sec/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / max(args.steps, 1), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'char config (hidden 1024, 16 heads, 6+6 blocks, GLU 4096, tied V=3900), beam %d, '
+                                   'max_target_length %d, %d x %.0f s synthetic fbank utterances per GPU per step '
+                                   '(T=%d stacked frames), random-init weights, %d decode steps taken'
+                                   % (args.beam, args.max_target_length, n, t_raw / 100.0, (t_raw + 2) // 3, Y.shape[1]),
+                       'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world},
+        }
+        # ---- roofline of the dominant kernel: HIP events around every launch of one extra pass ----
+        eng.set_profile(True)
+        eng.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
+        prof = eng.get_profile()
+        eng.set_profile(False)
+        tot_ms = sum(p['ms'] for p in prof) or 1.0
+        dom = max(prof, key=lambda p: p['ms'])
+        ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['flops'] > 0 else dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+        is_mfma = dom['flops'] > 0 and dom['name'].startswith('gemm')
+        out['roofline'] = {
+            'kernel': dom['name'], 'bound': 'mfma' if is_mfma else 'hbm', 'achieved': ach,
+            'peak': PEAK_F32_MFMA_TFLOPS if is_mfma else PEAK_HBM_GBS, 'unit': 'TFLOP/s' if is_mfma else 'GB/s',
+            'frac': ach / (PEAK_F32_MFMA_TFLOPS if is_mfma else PEAK_HBM_GBS), 'traffic': None,
+            'launches': dom['launches'], 'avg_us': 1000.0 * dom['ms'] / max(dom['launches'], 1),
+            'share_of_kernel_time': dom['ms'] / tot_ms,
+        }
+        out['kernels'] = [{'name': p['name'], 'ms': round(p['ms'], 3), 'launches': p['launches'],
+                           'tflops': round(p['flops'] / (p['ms'] * 1e-3) / 1e12, 2) if p['ms'] > 0 else 0.0,
+                           'gbs': round(p['bytes'] / (p['ms'] * 1e-3) / 1e9, 1) if p['ms'] > 0 else 0.0}
+                          for p in sorted(prof, key=lambda p: -p['ms'])]
+        if world == 1 and not args.no_cpu_baseline:
+            cb, Yc = cpu_baseline(cfg, W, raw, min(args.cpu_sample_utts, n))
+            m = min(Yc.shape[1], Y.shape[1])
+            cb['hypotheses_match_gpu'] = bool(np.array_equal(Yc[:, :m], Y[:Yc.shape[0], :m]))
+            out['cpu_baseline'] = cb
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

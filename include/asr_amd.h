@@ -1,0 +1,158 @@
+/*
+ * asr_amd.h -- C ABI of libasr_amd.so: the MI355X (gfx950) implementation of the batched
+ * inference path of shiyuzh2007/ASR (fbank frame stacking -> encoder -> beam-search decoder).
+ *
+ * The reference has no FFI for this path: it sits behind `Evaluator.beam_search(X)`
+ * (transformer/evaluate.py:46-47), i.e. one `sess.run(model.prediction, feed_dict)` per batch.
+ * Each entry point below names the reference interface it stands in for (file:line relative to
+ * /root/reference/transformer/).  The Python host (asr_amd/) binds these with ctypes.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a
+ * non-zero asr_status otherwise; asr_last_error() returns the message of the last failure on
+ * that handle (or of the last failed asr_create when handle == NULL).  A handle owns one GPU's
+ * weights, K/V caches and workspaces; it is not thread-safe; calls block until outputs are
+ * valid.  Host-pointer arguments are ordinary pageable memory unless a name ends in `_dev`.
+ */
+#ifndef ASR_AMD_H
+#define ASR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct asr_handle asr_handle;
+
+enum asr_status {
+    ASR_OK = 0,
+    ASR_ERR_ARG = 1,        /* bad argument / shape                     */
+    ASR_ERR_HIP = 2,        /* a HIP runtime call or kernel failed      */
+    ASR_ERR_WEIGHTS = 3,    /* unknown / missing / mis-shaped variable  */
+    ASR_ERR_STATE = 4,      /* call order (e.g. decode before finalize) */
+    ASR_ERR_CAPACITY = 5    /* output buffer too small                  */
+};
+
+enum asr_ff_activation { ASR_FF_RELU = 0, ASR_FF_GLU = 1, ASR_FF_SIGMOID = 2, ASR_FF_TANH = 3, ASR_FF_SWISH = 4 };
+
+/* Model + search configuration: the YAML keys read by the inference graph
+ * (model.py:19-45,434-442; config_template_*.yaml). */
+typedef struct asr_config {
+    int32_t input_dim;                   /* train.input_dim (320 = 80 x (3+1))            */
+    int32_t hidden_units;                /* hidden_units                                  */
+    int32_t num_heads;                   /* num_heads (hidden_units / num_heads must be 64) */
+    int32_t num_blocks;                  /* num_blocks (encoder and decoder)              */
+    int32_t dst_vocab_size;              /* dst_vocab_size                                */
+    int32_t ff_activation;               /* enum asr_ff_activation (ff_activation)        */
+    int32_t scale_embedding;             /* scale_embedding                               */
+    int32_t tie_embedding_and_softmax;   /* tie_embedding_and_softmax                     */
+    int32_t beam_size;                   /* test.beam_size (1..32)                        */
+    int32_t max_target_length;           /* test.max_target_length                        */
+    float   lp_alpha;                    /* test.lp_alpha                                 */
+    int32_t device;                      /* HIP device ordinal this handle lives on       */
+    int32_t reserved[4];                 /* must be zero                                  */
+} asr_config;
+
+/* Number of HIP devices visible to this process (0 when there is none or on error).  Replaces the
+ * `/gpu:%d` device list of Model.__init__ (model.py:27). */
+int asr_device_count(void);
+
+/* Replaces: `eval(config.model)(config, num_gpus)` + `build_test_model()` for ONE device
+ * (evaluate.py:26-27; model.py:162-204). */
+int asr_create(const asr_config* cfg, asr_handle** out);
+void asr_destroy(asr_handle* h);
+const char* asr_last_error(const asr_handle* h);
+
+/* Replaces: `model.saver.restore(sess, latest_checkpoint)` (evaluate.py:36).  `tf_var_name` is the
+ * TensorFlow variable name, `data` float32 host memory of `shape[0..ndim)`.
+ * Unknown names are rejected with ASR_ERR_WEIGHTS unless they are optimizer slots / counters
+ * (`.../Adam`, `.../Adam_1`, `beta1_power`, `beta2_power`, `global_step`), which are ignored. */
+int asr_load_tensor(asr_handle* h, const char* tf_var_name, const float* data,
+                    const int64_t* shape, int32_t ndim);
+/* Fails with ASR_ERR_WEIGHTS (message lists the names) while any graph variable is missing;
+ * on success packs the weights into their device layouts. */
+int asr_finalize_weights(asr_handle* h);
+
+/* Replaces: `Evaluator.beam_search(X)` for one device shard (evaluate.py:46-47; model.py:176-178):
+ * X [n, t, d] float32 row-major, all-zero rows are padding (model.py:450).  Y receives int32
+ * [n, *len_out] row-major (row stride *len_out), hypotheses right-padded with 3;
+ * y_capacity = number of int32 elements Y can hold (n * (max_target_length + 1) always suffices).
+ * n == 0 returns *len_out = 0 (model.py:184-187). */
+int asr_decode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d,
+               int32_t* Y, int64_t y_capacity, int32_t* len_out);
+
+/* Same, with X already resident in this device's memory (what bench.py times).  If
+ * raw_frames > 0, X_dev is instead RAW fbank [n, raw_frames, raw_dim] and the frame-stacking
+ * front end (left, right, sub) runs on the device first (third_party/feat_convert/io/fea.py:142-149),
+ * giving t = ceil(raw_frames / sub), d = raw_dim * (left + right + 1). */
+int asr_decode_dev(asr_handle* h, const float* X_dev, int32_t n, int32_t t, int32_t d,
+                   int32_t raw_frames, int32_t raw_dim, int32_t left, int32_t right, int32_t sub,
+                   int32_t* Y, int64_t y_capacity, int32_t* len_out);
+
+/* Front end alone.  Replaces tf_fea_splice (+ the `sub` subsampling implied by the
+ * `feats.scp.left3_sub3` inputs): feats [n_frames, dim] -> out [ceil(n_frames/sub), dim*(left+right+1)]. */
+int asr_stack_frames(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim,
+                     int32_t left, int32_t right, int32_t sub, float* out);
+
+/* Parity probe.  Replaces `Model.encoder(X)` (model.py:206-209,444-490): X [n,t,d] ->
+ * enc_out [n,t,hidden_units], pad_out (optional) [n,t] int32 (1 = padded frame). */
+int asr_encode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d,
+               float* enc_out, int32_t* pad_out);
+
+/* Parity probe: asr_decode that also returns, for the first `trace_steps` decode steps,
+ * the pre-softmax logits [trace_steps, n*beam, vocab] and the pruned beam scores / tokens /
+ * parents [trace_steps, n*beam] (model.py:277-301).  Any trace pointer may be NULL. */
+int asr_decode_trace(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d,
+                     int32_t* Y, int64_t y_capacity, int32_t* len_out, int32_t trace_steps,
+                     float* logits, float* scores, int32_t* tokens, int32_t* parents);
+
+/* ---- single-kernel probes (host pointers; for the per-kernel parity tests) -------------- */
+
+/* utils.dense (utils.py:546-557): y[m,n] = x[m,k] . w[n,k]^T + bias[n] (bias may be NULL).
+ * split_k >= 1 exercises the split-K path (partials reduced in fixed order). */
+int asr_op_dense(asr_handle* h, const float* x, const float* w, const float* bias,
+                 int32_t m, int32_t n, int32_t k, int32_t split_k, float* y);
+/* ff_hidden's first dense with GLU (utils.py:559-561; model.py:441):
+ * y[m,n] = (x.w1^T + b1) * sigmoid(x.w2^T + b2). */
+int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float* b1,
+                     const float* w2, const float* b2, int32_t m, int32_t n, int32_t k, float* y);
+/* utils.residual (utils.py:494-507; common_layers.py:333-338):
+ * y = layer_norm(x + delta + dbias, eps 1e-6) * scale + bias; dbias may be NULL. */
+int asr_op_add_layer_norm(asr_handle* h, const float* x, const float* delta, const float* dbias,
+                          const float* scale, const float* bias, int32_t rows, int32_t hidden,
+                          float* y);
+/* tf.contrib.layers.layer_norm over (t,hidden) per utterance + add_timing_signal_1d
+ * (model.py:453,456): x [n,t,hidden] -> y. */
+int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, const float* beta,
+                             int32_t n, int32_t t, int32_t hidden, float* y);
+/* Encoder self-attention core (utils.py:624-631; common_attention.py:295-334): qkv [n,t,3*hidden]
+ * (q | k | v, q NOT yet scaled), pad [n,t] int32 -> ctx [n,t,hidden]. */
+int asr_op_encoder_attention(asr_handle* h, const float* qkv, const int32_t* pad,
+                             int32_t n, int32_t t, float* ctx);
+/* model.test_output (model.py:345-347): logits [rows,vocab] -> top-k of log_softmax,
+ * ordered by (value desc, index asc): values [rows,k], indices [rows,k]. */
+int asr_op_log_softmax_topk(asr_handle* h, const float* logits, int32_t rows, int32_t vocab,
+                            int32_t k, float* values, int32_t* indices);
+/* One pruning step (model.py:280-301): scores [b*k], finished [b*k] (0/1), cand_scores /
+ * cand_tokens [b*k, k] -> new_scores, tokens, parents (global row index), finished_out. */
+int asr_op_beam_step(asr_handle* h, const float* scores, const int32_t* finished,
+                     const float* cand_scores, const int32_t* cand_tokens, int32_t b, int32_t k,
+                     float* new_scores, int32_t* tokens, int32_t* parents, int32_t* finished_out);
+
+/* ---- instrumentation ---------------------------------------------------------------------- */
+
+/* mode 0: normal.  mode 1: bracket every kernel launch of subsequent calls with HIP events on the
+ * handle's stream and accumulate per-kernel-class time (serialises the host; for bench.py's
+ * roofline leg and nothing else). */
+int asr_set_profile(asr_handle* h, int32_t mode);
+/* Returns up to `cap` classes accumulated since the last asr_set_profile(h, 1):
+ * names[i] (static strings), total milliseconds, launch counts, algorithmic FLOPs and bytes. */
+int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, int64_t* launches,
+                    double* flops, double* bytes, int32_t* n_out);
+/* Device-memory footprint of the handle in bytes (weights + caches + workspaces). */
+int64_t asr_device_bytes(const asr_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_AMD_H */
