@@ -1,0 +1,114 @@
+"""Multi-GPU data parallelism for the inference path: one process per GPU (torch.distributed;
+backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+The reference's only cross-device step is the pad-with-3 + concat of per-tower predictions
+(model.py:192-201); utterances are independent, so length-bucketed batches are dealt to ranks by
+cost, each rank decodes its batches with its own weight replica and K/V cache, and ONE all_gather of a
+fixed-width int32 buffer per evaluation restores the original utterance order.  No tensor parallelism.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def bucket_batches(lengths, tokens_per_batch, bucket_min=50, bucket_max=10000, bucket_step=10):
+    """Indices of utterances grouped like DataReader.get_test_batches_with_buckets
+    (utils.py:285-323): 10-frame buckets on the stacked length, a bucket is closed once its frame
+    count exceeds `tokens_per_batch`, leftovers in bucket order.  Returns a list of index lists."""
+    buckets = list(range(bucket_min, bucket_max, bucket_step))
+    caches = {}
+    out = []
+    for i, sl in enumerate(lengths):
+        b = next((x for x in buckets if sl < x), None)
+        if b is None:
+            raise ValueError('The sequence is too long: (%d)' % sl)
+        c = caches.setdefault(b, [[], 0])
+        c[0].append(i)
+        c[1] += int(sl)
+        if c[1] > tokens_per_batch:
+            out.append(c[0])
+            caches[b] = [[], 0]
+    for b in buckets:
+        if b in caches and caches[b][0]:
+            out.append(caches[b][0])
+    return out
+
+
+def batch_cost(n, t, beam, max_target_length, hidden=1024, blocks=6):
+    """Rough FLOP cost of one batch: encoder + cross K/V + worst-case decode."""
+    steps = min(t + 50, max_target_length) + 1
+    enc = n * blocks * (32.0 * t * hidden * hidden + 4.0 * t * t * hidden) + n * blocks * 4.0 * t * hidden * hidden
+    dec = n * beam * steps * blocks * (36.0 * hidden * hidden + 4.0 * hidden * (steps / 2 + t))
+    return enc + dec
+
+
+def assign_batches(costs, world_size):
+    """Longest-processing-time-first deal of batches to ranks; returns rank -> list of batch indices."""
+    order = sorted(range(len(costs)), key=lambda i: -costs[i])
+    load = [0.0] * world_size
+    owner = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda x: (load[x], x))
+        owner[r].append(i)
+        load[r] += costs[i]
+    for r in range(world_size):
+        owner[r].sort()
+    return owner
+
+
+def gather_hypotheses(local_ids, local_hyps, n_total, width, group=None, device=None):
+    """all_gather of (utterance index, hypothesis) rows -> int32 [n_total, width] in original order on
+    every rank.  `local_hyps` is a list of 1-D int32 arrays (already cut or padded with 3)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    cap = torch.tensor([len(local_ids)], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
+    cap = int(cap.item())
+    buf = np.full((cap, width + 1), 3, np.int32)
+    buf[:, 0] = -1
+    for row, (i, h) in enumerate(zip(local_ids, local_hyps)):
+        buf[row, 0] = i
+        h = np.asarray(h, np.int32)[:width]
+        buf[row, 1:1 + len(h)] = h
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    if world > 1:
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        allrows = torch.cat(parts, dim=0).cpu().numpy()
+    else:
+        allrows = t.cpu().numpy()
+    out = np.full((n_total, width), 3, np.int32)
+    seen = np.zeros(n_total, bool)
+    for row in allrows:
+        if row[0] >= 0:
+            out[row[0]] = row[1:]
+            seen[row[0]] = True
+    if not seen.all():
+        raise RuntimeError('hypotheses missing for utterances %s' % np.nonzero(~seen)[0][:8].tolist())
+    return out
+
+
+def decode_sharded(decode_fn, feats, tokens_per_batch, beam, max_target_length, rank=0, world_size=1,
+                   group=None, device=None):
+    """Bucket `feats` (list of [T_u, D] arrays) by length, deal the batches over ranks, decode this
+    rank's batches with `decode_fn(X) -> Y`, gather.  Returns int32 [len(feats), max_target_length+1]."""
+    lengths = [len(f) for f in feats]
+    batches = bucket_batches(lengths, tokens_per_batch)
+    costs = [batch_cost(len(b), max(lengths[i] for i in b), beam, max_target_length) for b in batches]
+    mine = assign_batches(costs, world_size)[rank]
+    ids, hyps = [], []
+    for bi in mine:
+        idx = batches[bi]
+        tmax = max(lengths[i] for i in idx)
+        X = np.zeros((len(idx), tmax, feats[idx[0]].shape[1]), np.float32)
+        for r, i in enumerate(idx):
+            X[r, :lengths[i]] = feats[i]
+        Y = decode_fn(X)
+        for r, i in enumerate(idx):
+            ids.append(i)
+            hyps.append(Y[r])
+    return gather_hypotheses(ids, hyps, len(feats), max_target_length + 1, group=group, device=device)

@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharding + hypothesis gather (asr_amd/dist.py).
+The decode function is a deterministic stand-in (the HIP path needs a GPU); what is under test is
+the bucketing, the deal of batches to ranks, and the gather restoring utterance order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_decode(X):
+    # hypothesis = function of the utterance's own content and length only
+    n = X.shape[0]
+    out = np.full((n, 6), 3, np.int32)
+    for i in range(n):
+        t = int((np.abs(X[i]).sum(-1) > 0).sum())
+        out[i, :3] = [t % 50 + 4, int(abs(X[i, 0, 0]) * 1000) % 40 + 4, X.shape[1] % 30 + 4]
+    return out
+
+
+def _feats():
+    rng = np.random.default_rng(0)
+    lens = [55, 61, 120, 58, 49, 130, 131, 57, 300, 62, 63, 64]
+    return [rng.standard_normal((t, 8)).astype(np.float32) for t in lens]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from asr_amd import dist as D
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    Y = D.decode_sharded(_fake_decode, _feats(), tokens_per_batch=100, beam=2, max_target_length=9, rank=rank,
+                         world_size=world)
+    q.put((rank, Y.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketing_and_assignment_cover_everything():
+    sys.path.insert(0, ROOT)
+    from asr_amd import dist as D
+    lens = [len(f) for f in _feats()]
+    batches = D.bucket_batches(lens, 100)
+    assert sorted(sum(batches, [])) == list(range(len(lens)))
+    for b in batches:                                            # one 10-frame bucket per batch
+        assert len({(lens[i] - 50) // 10 if lens[i] >= 50 else -1 for i in b}) == 1
+    costs = [D.batch_cost(len(b), max(lens[i] for i in b), 10, 200) for b in batches]
+    own = D.assign_batches(costs, 3)
+    assert sorted(sum(own, [])) == list(range(len(batches)))
+    loads = [sum(costs[i] for i in o) for o in own]
+    assert max(loads) < 2.0 * (sum(costs) / 3) + max(costs)
+
+
+def test_world_size_2_gloo_matches_single_process():
+    sys.path.insert(0, ROOT)
+    from asr_amd import dist as D
+    single = D.decode_sharded(_fake_decode, _feats(), tokens_per_batch=100, beam=2, max_target_length=9)
+    assert single.shape == (12, 10)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == single.tolist()

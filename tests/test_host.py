@@ -1,0 +1,167 @@
+"""CPU tests of the host-side mirror of evaluate.py's harness (no GPU, no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import yaml
+
+from asr_amd import ark, weights
+from asr_amd.utils import AttrDict, DataReader, expand_feed_dict, shard_bounds
+from oracle import asr_oracle as O
+from tests.helpers import product_config, tiny_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_attrdict_semantics():
+    d = AttrDict({'a': 1, 'test': {'beam_size': 13, 'set1': {'src_path': 'x'}}})
+    assert d.a == 1 and d.missing is None                      # utils.py:35-37
+    assert isinstance(d.test, AttrDict) and d.test.beam_size == 13
+    assert d.test.set1.src_path == 'x' and d.test.nope is None
+    assert [k for k in d.test if k.startswith('set')] == ['set1']
+
+
+def test_shipped_configs_parse_and_carry_the_reference_keys():
+    cdir = os.path.join(ROOT, 'configs')
+    names = sorted(f for f in os.listdir(cdir) if f.endswith('.yaml'))
+    assert len(names) >= 5
+    vocab = {}
+    for n in names:
+        cfg = AttrDict(yaml.safe_load(open(os.path.join(cdir, n))))
+        assert cfg.model == 'Transformer' and cfg.hidden_units == 1024 and cfg.num_heads == 16 and cfg.num_blocks == 6
+        assert cfg.ff_activation == 'glu' and cfg.train.input_dim == 320 and cfg.test.max_target_length == 200
+        vocab[n] = cfg.dst_vocab_size
+        assert set(weights.variable_shapes(cfg)) == set(O.variable_shapes(O.make_config(dst_vocab_size=cfg.dst_vocab_size)))
+    assert {3900, 1388, 28444, 3205} <= set(vocab.values())   # char / pinyin / word / SEAME
+
+
+def test_expand_feed_dict_and_shards():
+    X = np.arange(10)[:, None]
+    fd = expand_feed_dict({('a', 'b', 'c', 'd'): X, 'k': 5})
+    assert [len(fd[p]) for p in 'abcd'] == [3, 3, 2, 2] and fd['k'] == 5
+    assert np.array_equal(np.concatenate([fd[p] for p in 'abcd']), X)
+    assert shard_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    assert shard_bounds(10, 4) == O.expand_shards(10, 4)
+
+
+def _write_vocab(path, n):
+    with open(path, 'w', encoding='utf-8') as f:
+        for i, w in enumerate(['<PAD>', '<UNK>', '<S>', '</S>'] + ['w%d' % i for i in range(n - 4)] + ['extra']):
+            f.write('%s %d\n' % (w, 1000 - i))
+
+
+def test_ark_roundtrip_and_datareader_batching(tmp_path):
+    scp, arkf = str(tmp_path / 'feats.scp'), str(tmp_path / 'feats.ark')
+    rng = np.random.default_rng(0)
+    feats = [rng.standard_normal((t, 320)).astype(np.float32) for t in (55, 61, 120, 58, 49)]
+    w = ark.ArkWriter(scp)
+    for i, f in enumerate(feats):
+        w.write_next_utt(arkf, 'utt%d' % i, f)
+    w.close()
+    r = ark.ArkReader(scp)
+    assert len(r) == 5
+    for i, f in enumerate(feats):
+        uid, m, looped = r.read_next_utt()
+        assert uid == 'utt%d' % i and not looped and np.array_equal(m, f)
+    assert r.read_next_utt()[2] is True                           # loops after the last entry (ark.py:164-166)
+    assert np.array_equal(r.read_utt('utt3'), feats[3])
+
+    vocab = str(tmp_path / 'vocab.txt')
+    _write_vocab(vocab, 20)
+    cfg = product_config(tiny_config(dst_vocab_size=20))
+    cfg['dst_vocab'] = vocab
+    dr = DataReader(cfg)
+    assert dr.idx2dst[3] == '</S>' and len(dr.idx2dst) == 20
+    batches = list(dr.get_test_batches(scp, 2))
+    assert [b[1] for b in batches] == [['utt0', 'utt1'], ['utt2', 'utt3'], ['utt4']]
+    X = batches[0][0]
+    assert X.shape == (2, 61, 320) and X.dtype == np.float32 and np.all(X[0, 55:] == 0) and np.array_equal(X[1], feats[1])
+    bb = list(dr.get_test_batches_with_buckets(scp, 100))
+    # buckets: 55,58 -> bucket 60 (emitted once > 100 frames); 61 -> 70; 120 -> 130 (emitted at once); 49 -> 50
+    assert [b[1] for b in bb] == [['utt2'], ['utt0', 'utt3'], ['utt4'], ['utt1']]
+    assert sorted(sum([b[1] for b in bb], [])) == ['utt%d' % i for i in range(5)]
+    assert dr.indices_to_words(np.array([[5, 6, 3, 7], [3, 3, 3, 3], [4, 4, 4, 4]])) == ['w1 w2', '', 'w0 w0 w0 w0']
+
+
+def test_ark_double_and_compressed(tmp_path):
+    import struct
+    p = str(tmp_path / 'x.ark')
+    m = np.arange(6, dtype=np.float64).reshape(2, 3)
+    with open(p, 'wb') as f:
+        f.write(b'a ')
+        off1 = f.tell()
+        f.write(b'\0BDM ' + struct.pack('<bi', 4, 2) + struct.pack('<bi', 4, 3) + m.tobytes())
+        f.write(b'b ')
+        off2 = f.tell()
+        # BCM2: 16-bit, value = raw * range / 65535 + min
+        raw = np.array([[0, 100], [-200, 32767]], dtype='<i2')
+        f.write(b'\0BCM2 ' + struct.pack('<ffii', -1.0, 4.0, 2, 2) + raw.tobytes())
+    with open(str(tmp_path / 'x.scp'), 'w') as f:
+        f.write('a %s:%d\nb %s:%d\n' % (p, off1, p, off2))
+    r = ark.ArkReader(str(tmp_path / 'x.scp'))
+    assert np.array_equal(r.read_utt('a'), m.astype(np.float32))
+    assert np.allclose(r.read_utt('b'), raw.astype(np.float32) * 4.0 / 65535.0 - 1.0)
+
+
+def test_random_init_follows_q11_and_checkpoint_io(tmp_path):
+    cfg = product_config(tiny_config())
+    W = weights.random_init(cfg, seed=3)
+    shapes = weights.variable_shapes(cfg)
+    assert set(W) == set(shapes)
+    k = W['encoder/block_0/encoder_self_attention/qkv_transform/kernel']
+    lim = np.sqrt(6.0 / (k.shape[0] + k.shape[1]))
+    assert k.dtype == np.float32 and np.abs(k).max() <= lim and np.abs(k).max() > 0.9 * lim
+    assert np.all(W['encoder/LayerNorm/gamma'] == 1) and np.all(W['encoder/src_change/bias'] == 0)
+    d = tmp_path / 'model_dir'
+    d.mkdir()
+    extra = dict(W)
+    extra['global_step'] = np.array(7, np.int64)
+    extra['encoder/src_change/kernel/Adam'] = np.zeros_like(W['encoder/src_change/kernel'])
+    extra['beta1_power'] = np.float32(0.5)
+    weights.save_npz(str(d / 'averaged.ckpt-0'), extra)
+    (d / 'checkpoint').write_text('model_checkpoint_path: "averaged.ckpt-0"\nall_model_checkpoint_paths: "averaged.ckpt-0"\n')
+    path = weights.latest_checkpoint(str(d))
+    assert path.endswith('averaged.ckpt-0')
+    got = weights.load_checkpoint(path)
+    assert set(got) == set(W) and all(np.array_equal(got[k], W[k]) for k in W)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports every function include/asr_amd.h declares."""
+    hdr = open(os.path.join(ROOT, 'include', 'asr_amd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = set(re.findall(r'\b(asr_[a-z_0-9]+)\s*\(', hdr))
+    assert len(names) >= 20 and 'asr_decode' in names and 'asr_op_dense' in names
+    from asr_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(lib, n), 'missing export %s' % n
+    # and the ctypes binding covers all of them
+    src = open(os.path.join(ROOT, 'asr_amd', '_lib.py')).read()
+    for n in names:
+        assert "'%s'" % n in src, 'asr_amd/_lib.py does not bind %s' % n
+
+
+def test_argument_errors_without_gpu():
+    """asr_create must fail loudly (not fall back) when no GPU is visible or the config is unsupported."""
+    from asr_amd import _lib
+    from asr_amd.model import Engine
+    bad = product_config(tiny_config(hidden_units=96, num_heads=2))      # d_head != 64
+    with pytest.raises(_lib.AsrError):
+        Engine(bad, 0)
+    if _lib.lib.asr_device_count() == 0:
+        with pytest.raises(_lib.AsrError) as ei:
+            Engine(product_config(tiny_config()), 0)
+        assert 'HIP device' in str(ei.value)
+
+
+def test_product_path_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, 'asr_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(root, f)).read()
+                assert 'oracle' not in re.sub(r'#.*', '', src).replace('asr_oracle', 'oracle') or \
+                    not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
