@@ -98,7 +98,9 @@ struct SelfAttnArgs {
     const int32_t* done;
     float* ctx;            // [R, hidden]
     int b, k, heads, width;
+    int lds_stride;        // >= (max position this decode can reach) + 1, <= width: row pitch of the LDS score / ancestry tables
 };
+size_t self_attention_lds_bytes(int k, int lds_stride);
 hipError_t launch_decoder_self_attention(const SelfAttnArgs& a, hipStream_t s);
 struct CrossAttnArgs {
     const float* qpart;    // [nsplit][R][hidden] partial q projections

@@ -139,49 +139,29 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
 
 // ------------------------------------------------------------------------------------------------
 // Decoder self-attention at position `pos` (model.py:588-600 with reserve_last; no mask).
-// One wave per (row, head); 16 lanes x 16 B cover one 64-float K or V row, 4 positions per pass.
-// The row's own k/v of position `pos` are appended to the cache (slot = the row's beam index);
-// history positions j < pos are read from slot anc[row][j] (see beam_step_kernel).
+// One workgroup per (utterance, head) serves all K beams.  The beams' own k/v of position `pos`
+// are appended to the cache (slot = beam index); history position j < pos of beam b is read from
+// slot anc[b][j] (see beam_step_kernel).  Beams of one utterance share most of their history, so
+// the K loads of a 16-lane group (one history position, all beams) mostly repeat one 256-B row and
+// are served by the CU's L1: HBM/L2 traffic is the number of DISTINCT (position, slot) rows.
+// A 16-lane group covers one 64-float row with 16-B loads; the KB loads of a position are issued
+// together (memory-level parallelism instead of one dependent load per pass).
 // ------------------------------------------------------------------------------------------------
+template <int KB>
 __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArgs a)
 {
     if (*a.done) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sc_all = reinterpret_cast<float*>(smem_raw);            // [4][width]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = lane >> 4, c = lane & 15;
-    const int hidden = a.heads * 64;
-    const int total = a.b * a.k * a.heads;
-    int g = blockIdx.x * 4 + wave;
-    const bool active = g < total;
-    if (!active) g = total - 1;
-    const int r = g / a.heads, h = g - r * a.heads;
-    const int u = r / a.k, slot = r - u * a.k;
+    const int h = blockIdx.x, u = blockIdx.y;
+    const int K = a.k, hidden = a.heads * 64, width = a.width, ls = a.lds_stride;
     const int pos = *a.pos;
-    const int32_t* anc = ((pos & 1) ? a.anc1 : a.anc0) + (size_t)r * a.width;
-    float* sc = sc_all + wave * a.width;
-
-    f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, v4 = q4;
-    {
-        const size_t rowoff = (size_t)r * 3 * hidden + h * 64 + c * 4;
-        for (int z = 0; z < a.nsplit; ++z) {
-            const float* p = a.qkv + z * a.split_stride + rowoff;
-            q4 += *reinterpret_cast<const f32x4*>(p);
-            k4 += *reinterpret_cast<const f32x4*>(p + hidden);
-            v4 += *reinterpret_cast<const f32x4*>(p + 2 * hidden);
-        }
-        const float* bp = a.bias + h * 64 + c * 4;
-        q4 += *reinterpret_cast<const f32x4*>(bp);
-        k4 += *reinterpret_cast<const f32x4*>(bp + hidden);
-        v4 += *reinterpret_cast<const f32x4*>(bp + 2 * hidden);
-        q4 = q4 * 0.125f;                                          // utils.py:628 (after the bias, Q3)
-    }
-    const size_t ubase = (size_t)u * a.width;
-    if (active && grp == 0) {
-        const size_t off = ((ubase + pos) * a.k + slot) * hidden + h * 64 + c * 4;
-        *reinterpret_cast<f32x4*>(a.kcache + off) = k4;
-        *reinterpret_cast<f32x4*>(a.vcache + off) = v4;
-    }
+    float* qs = reinterpret_cast<float*>(smem_raw);        // [KB][64]
+    float* vnew = qs + KB * 64;                            // [KB][64]
+    float* red = vnew + KB * 64;                           // [4][KB][64]
+    float* sc = red + 4 * KB * 64;                         // [KB][ls]
+    int32_t* ancs = reinterpret_cast<int32_t*>(sc + KB * ls);   // [KB][ls]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = tid >> 4, c = tid & 15;
 
     auto dot16 = [&](const f32x4& x, const f32x4& y) {
         float d = (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
@@ -189,40 +169,104 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
         return d;
     };
 
-    const float s_pos = dot16(q4, k4);
-    for (int j0 = 0; j0 < pos; j0 += 4) {
-        const int j = j0 + grp;
-        const bool valid = j < pos;
-        f32x4 kk = {0.f, 0.f, 0.f, 0.f};
-        if (valid) {
-            const int sl = anc[j];
-            kk = *reinterpret_cast<const f32x4*>(a.kcache + ((ubase + j) * a.k + sl) * hidden + h * 64 + c * 4);
+    // ---- q, k, v of the new position: reduce the split-K slabs, add the bias, scale q (utils.py:628, Q3)
+    for (int i = tid; i < KB * 16; i += 256) {
+        const int kb = i >> 4;
+        f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, v4 = q4;
+        if (kb < K) {
+            const size_t rowoff = (size_t)(u * K + kb) * 3 * hidden + h * 64 + c * 4;
+            for (int z = 0; z < a.nsplit; ++z) {
+                const float* p = a.qkv + z * a.split_stride + rowoff;
+                q4 += *reinterpret_cast<const f32x4*>(p);
+                k4 += *reinterpret_cast<const f32x4*>(p + hidden);
+                v4 += *reinterpret_cast<const f32x4*>(p + 2 * hidden);
+            }
+            const float* bp = a.bias + h * 64 + c * 4;
+            q4 += *reinterpret_cast<const f32x4*>(bp);
+            k4 += *reinterpret_cast<const f32x4*>(bp + hidden);
+            v4 += *reinterpret_cast<const f32x4*>(bp + 2 * hidden);
+            q4 = q4 * 0.125f;
+            const size_t off = (((size_t)u * width + pos) * K + kb) * hidden + h * 64 + c * 4;
+            *reinterpret_cast<f32x4*>(a.kcache + off) = k4;
+            *reinterpret_cast<f32x4*>(a.vcache + off) = v4;
         }
-        const float d = dot16(q4, kk);
-        if (valid && c == 0) sc[j] = d;
+        reinterpret_cast<f32x4*>(qs)[kb * 16 + c] = q4;
+        reinterpret_cast<f32x4*>(vnew)[kb * 16 + c] = v4;
+        const float d = dot16(q4, k4);
+        if (c == 0) sc[kb * ls + pos] = d;
+    }
+    {
+        const int32_t* anc = ((pos & 1) ? a.anc1 : a.anc0) + (size_t)u * K * width;
+        for (int i = tid; i < K * pos; i += 256) {
+            const int kb = i / pos, j = i - kb * pos;
+            ancs[kb * ls + j] = anc[(size_t)kb * width + j];
+        }
     }
     __syncthreads();
-    float m = s_pos;
-    for (int j = lane; j < pos; j += 64) m = fmaxf(m, sc[j]);
-    m = wave_max(m);
-    float sum = 0.f;
-    for (int j = lane; j < pos; j += 64) { const float e = expf(sc[j] - m); sc[j] = e; sum += e; }
-    const float e_pos = expf(s_pos - m);
-    sum = wave_sum(sum) + e_pos;
-    __syncthreads();
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < pos; j0 += 4) {
-        const int j = j0 + grp;
-        if (j < pos) {
-            const int sl = anc[j];
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(a.vcache + ((ubase + j) * a.k + sl) * hidden + h * 64 + c * 4);
-            acc += vv * (sc[j] / sum);
+
+    // ---- scores: group `grp` takes history positions j = grp, grp+16, ...
+    const size_t head_off = (size_t)h * 64 + c * 4;
+    for (int j = grp; j < pos; j += 16) {
+        const float* kbase = a.kcache + ((size_t)u * width + j) * K * hidden + head_off;
+        f32x4 kk[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            kk[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kb < K) kk[kb] = *reinterpret_cast<const f32x4*>(kbase + (size_t)ancs[kb * ls + j] * hidden);
         }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const float d = dot16(reinterpret_cast<const f32x4*>(qs)[kb * 16 + c], kk[kb]);
+            if (c == 0) sc[kb * ls + j] = d;
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax over positions 0..pos, one wave per beam
+    for (int kb = wave; kb < K; kb += 4) {
+        float* s = sc + kb * ls;
+        float m = -INFINITY;
+        for (int j = lane; j <= pos; j += 64) m = fmaxf(m, s[j]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int j = lane; j <= pos; j += 64) { const float e = expf(s[j] - m); s[j] = e; sum += e; }
+        sum = wave_sum(sum);
+        for (int j = lane; j <= pos; j += 64) s[j] = s[j] / sum;
+    }
+    __syncthreads();
+
+    // ---- context: per-group partial sums over its positions, then groups -> wave -> workgroup
+    f32x4 o[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) o[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = grp; j < pos; j += 16) {
+        const float* vbase = a.vcache + ((size_t)u * width + j) * K * hidden + head_off;
+        f32x4 vv[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            vv[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kb < K) vv[kb] = *reinterpret_cast<const f32x4*>(vbase + (size_t)ancs[kb * ls + j] * hidden);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) o[kb] += vv[kb] * sc[kb * ls + j];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { acc[j] += __shfl_xor(acc[j], 16); acc[j] += __shfl_xor(acc[j], 32); }
-    acc += v4 * (e_pos / sum);
-    if (active && grp == 0) *reinterpret_cast<f32x4*>(a.ctx + (size_t)r * hidden + h * 64 + c * 4) = acc;
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[kb][j] += __shfl_xor(o[kb][j], 16); o[kb][j] += __shfl_xor(o[kb][j], 32); }
+        if ((lane >> 4) == 0) reinterpret_cast<f32x4*>(red)[(wave * KB + kb) * 16 + c] = o[kb];
+    }
+    __syncthreads();
+    for (int i = tid; i < KB * 16; i += 256) {
+        const int kb = i >> 4, cc = i & 15;
+        if (kb < K) {
+            const f32x4* rp = reinterpret_cast<const f32x4*>(red);
+            f32x4 v = (rp[(0 * KB + kb) * 16 + cc] + rp[(1 * KB + kb) * 16 + cc]) +
+                      (rp[(2 * KB + kb) * 16 + cc] + rp[(3 * KB + kb) * 16 + cc]);
+            v += reinterpret_cast<const f32x4*>(vnew)[kb * 16 + cc] * sc[kb * ls + pos];
+            *reinterpret_cast<f32x4*>(a.ctx + (size_t)(u * K + kb) * hidden + h * 64 + cc * 4) = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,6 +383,23 @@ hipError_t launch_cross(const CrossAttnArgs& a, size_t lds, hipStream_t s)
     return hipGetLastError();
 }
 
+template <int KB>
+hipError_t launch_self(const SelfAttnArgs& a, size_t lds, hipStream_t s)
+{
+    auto kern = decoder_self_attention_kernel<KB>;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.heads, a.b), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads, float* ctx, hipStream_t s)
@@ -348,14 +409,26 @@ hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n,
     return hipGetLastError();
 }
 
+size_t self_attention_lds_bytes(int k, int lds_stride)
+{
+    const int kb = cross_kb(k);
+    return ((size_t)kb * 64 * 6 + (size_t)2 * kb * lds_stride) * sizeof(float);
+}
+
 hipError_t launch_decoder_self_attention(const SelfAttnArgs& a, hipStream_t s)
 {
-    const int total = a.b * a.k * a.heads;
-    if (total <= 0) return hipSuccess;
-    const size_t lds = (size_t)4 * a.width * sizeof(float);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(decoder_self_attention_kernel, dim3((total + 3) / 4), dim3(256), lds, s, a);
-    return hipGetLastError();
+    if (a.b <= 0) return hipSuccess;
+    const size_t lds = self_attention_lds_bytes(a.k, a.lds_stride);
+    if (lds > 150 * 1024 || a.k > ASR_MAX_BEAM || a.lds_stride > a.width || a.lds_stride < 2) return hipErrorInvalidValue;
+    switch (cross_kb(a.k)) {
+        case 1: return launch_self<1>(a, lds, s);
+        case 2: return launch_self<2>(a, lds, s);
+        case 4: return launch_self<4>(a, lds, s);
+        case 8: return launch_self<8>(a, lds, s);
+        case 12: return launch_self<12>(a, lds, s);
+        case 16: return launch_self<16>(a, lds, s);
+        default: return launch_self<32>(a, lds, s);
+    }
 }
 
 size_t cross_attention_lds_bytes(int k, int tp)

@@ -493,6 +493,7 @@ int run_decode_step(asr_handle* h, int n, int t)
             a.kcache = h->kcache[l]; a.vcache = h->vcache[l];
             a.anc0 = st.anc[0]; a.anc1 = st.anc[1]; a.pos = st.pos; a.done = st.done;
             a.ctx = h->dctx; a.b = n; a.k = K; a.heads = h->heads; a.width = st.width;
+            a.lds_stride = std::min(st.width, st.limit + 2);
             ProfScope ps(h, "decoder_self_attention", 0, 0);
             HIP_TRY(h, launch_decoder_self_attention(a, s));
         }
@@ -630,6 +631,8 @@ int check_xshape(asr_handle* h, int n, int t, int d)
     if (n > 0 && t < 1) return fail(h, ASR_ERR_ARG, "t must be >= 1");
     if ((size_t)((t + 63) / 64 * 64) * h->K * 4 + (size_t)h->K * 64 * 5 * 4 + 4096 > 150 * 1024)
         return fail(h, ASR_ERR_ARG, "t * beam_size exceeds the cross-attention LDS budget");
+    if (self_attention_lds_bytes(h->K, std::min(t + 50, (int)h->cfg.max_target_length) + 2) > 150 * 1024)
+        return fail(h, ASR_ERR_ARG, "min(t + 50, max_target_length) * beam_size exceeds the self-attention LDS budget");
     return ASR_OK;
 }
 
