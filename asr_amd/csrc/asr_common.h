@@ -13,7 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---- GEMM (gemm_f32.hip) -------------------------------------------------------------------
 enum GemmEpilogue {
     EPI_BIAS = 0,      // C = acc + bias (bias may be null)
-    EPI_GLU = 1,       // W rows interleaved in groups of 32 (value | gate); C[m, n/2] = (a+b1)*sigmoid(g+b2)
+    EPI_GLU = 1,       // W rows packed per 32: 16 value rows | 16 gate rows; C[m, n/2] = (a+b1)*sigmoid(g+b2)
     EPI_PARTIAL = 2,   // C[z][m][n] = acc of K-slice z (split-K slabs, reduced by the consumer)
     EPI_RELU = 3, EPI_SIGMOID = 4, EPI_TANH = 5, EPI_SWISH = 6   // 1-argument ff activations
 };
@@ -32,6 +32,8 @@ struct GemmArgs {
 hipError_t launch_gemm_f32(const GemmArgs& a, int tile_hint, hipStream_t s);
 // number of K-slices the decode-time projections should use for this shape (fills the chip)
 int gemm_pick_split_k(int M, int N, int K);
+// true: always use the register-staged main loop (the DMA-staged loop needs K % 32 == 0 and is the default when it applies)
+void gemm_force_reg_stage(bool on);
 
 // ---- row kernels (rowops.hip) ----------------------------------------------------------------
 hipError_t launch_frame_stack_lens(const float* raw, const int32_t* lens, int n, int raw_frames, int raw_dim, int left,
@@ -56,9 +58,8 @@ hipError_t launch_add_layer_norm_done(const float* resid, const float* part, int
 hipError_t launch_embed_pe(const float* E, const int32_t* preds0, const int32_t* preds1, int preds_stride,
                            const int32_t* pos_dev, const float* pe, float mult, int rows, int hidden, float* y,
                            const int32_t* done, hipStream_t s);
-// kv [n*t, 2*hidden] (k | v) -> kT [n][heads][64][tp], v [n][heads][t][64]
-hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int tp, int heads, float* kT, float* v,
-                                hipStream_t s);
+// kv [n*t, 2*hidden] (k | v) -> k, v [n][heads][t][64]
+hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, float* k, float* v, hipStream_t s);
 hipError_t launch_log_softmax_topk(const float* logits, int rows, int vocab, int k, float* values,
                                    int32_t* indices, const int32_t* done, hipStream_t s);
 
@@ -106,12 +107,11 @@ struct CrossAttnArgs {
     const float* qpart;    // [nsplit][R][hidden] partial q projections
     int nsplit; size_t split_stride;
     const float* qbias;    // [hidden]
-    const float* kT;       // [b][heads][64][tp]
+    const float* kc;       // [b][heads][t][64]
     const float* v;        // [b][heads][t][64]
     const int32_t* pad2;   // [b][t]
     const int32_t* done;
     float* ctx;            // [R, hidden]
-    int b, k, heads, t, tp;
+    int b, k, heads, t;
 };
 hipError_t launch_decoder_cross_attention(const CrossAttnArgs& a, hipStream_t s);
-size_t cross_attention_lds_bytes(int k, int tp);

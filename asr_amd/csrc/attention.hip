@@ -270,118 +270,162 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
 }
 
 // ------------------------------------------------------------------------------------------------
-// Decoder cross-attention (model.py:604-616): one workgroup per (utterance, head) serves all K beams.
-// K is stored transposed ([64][tp], built once per utterance by pack_cross_kv) so that lane = key
-// gives coalesced loads; V is [t][64] and is swept with 16 lanes x 16 B per key.
+// Decoder cross-attention (model.py:604-616): one workgroup per (utterance, head) serves all beams in
+// ONE pass over that utterance's K and V (flash-style, exact-f32 16x16x4 MFMA), so the kernel is bound
+// by the HBM stream of K/V and not by per-beam dot products.
+//   S^T[key][beam] = K.Q^T : A = K block (16 keys x 4 d), B = Q^T (4 d x 16 beams)
+//   O^T[d][beam]  += V^T.P^T: A = V^T (16 d x 4 keys),    B = P^T = the S^T accumulator itself
+// The MFMA k index is a summation label, so a lane feeds 4 consecutive d (resp. one key row) from one
+// 16-byte load.  The 4 waves take key blocks round-robin with an online softmax each and are merged
+// through LDS at the end.  NB = beam groups of 16 (beam_size <= 16*NB).
+// Mask: -1e9 on padded encoder positions exactly as the reference (common_attention.py:202); keys
+// beyond t (block padding) get -inf.
 // ------------------------------------------------------------------------------------------------
-template <int KB>
+template <int NB>
 __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnArgs a)
 {
     if (*a.done) return;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* qs = reinterpret_cast<float*>(smem_raw);        // [KB][64]
-    float* red = qs + KB * 64;                             // [4][KB][64]
-    float* sc = red + 4 * KB * 64;                         // [KB][tp]
+    __shared__ float wo[4][NB][64][17];
+    __shared__ float wm[4][NB][16], wl[4][NB][16];
     const int h = blockIdx.x, u = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hidden = a.heads * 64;
-    const int t = a.t, tp = a.tp, K = a.k;
+    const int g = lane >> 4, c = lane & 15;
+    const int hidden = a.heads * 64, t = a.t, K = a.k;
 
-    for (int i = tid; i < KB * 16; i += 256) {
-        const int kb = i >> 4, c = i & 15;
-        f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
-        if (kb < K) {
-            const size_t off = (size_t)(u * K + kb) * hidden + h * 64 + c * 4;
-            for (int z = 0; z < a.nsplit; ++z) q4 += *reinterpret_cast<const f32x4*>(a.qpart + z * a.split_stride + off);
-            q4 += *reinterpret_cast<const f32x4*>(a.qbias + h * 64 + c * 4);
-            q4 = q4 * 0.125f;
-        }
-        reinterpret_cast<f32x4*>(qs)[kb * 16 + c] = q4;
-    }
-    __syncthreads();
-
-    const float* kT = a.kT + ((size_t)u * a.heads + h) * 64 * tp;
-    for (int tt = tid; tt < tp; tt += 256) {
-        float acc[KB];
+    // q fragments: split-K slabs fetched four at a time (independent loads in flight), summed in slab order
+    f32x4 qf[NB][4], qb[4];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) acc[kb] = 0.f;
-#pragma unroll 4
-        for (int d0 = 0; d0 < 64; d0 += 4) {
-            const float x0 = kT[(size_t)(d0 + 0) * tp + tt], x1 = kT[(size_t)(d0 + 1) * tp + tt];
-            const float x2 = kT[(size_t)(d0 + 2) * tp + tt], x3 = kT[(size_t)(d0 + 3) * tp + tt];
+    for (int db = 0; db < 4; ++db) qb[db] = *reinterpret_cast<const f32x4*>(a.qbias + h * 64 + db * 16 + 4 * g);
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const f32x4 q4 = reinterpret_cast<const f32x4*>(qs)[kb * 16 + (d0 >> 2)];
-                acc[kb] = fmaf(q4[3], x3, fmaf(q4[2], x2, fmaf(q4[1], x1, fmaf(q4[0], x0, acc[kb]))));
+    for (int nb = 0; nb < NB; ++nb) {
+        const int beam = min(nb * 16 + c, K - 1);
+        const size_t off = (size_t)(u * K + beam) * hidden + h * 64 + 4 * g;
+        f32x4 acc4[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) acc4[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z0 = 0; z0 < a.nsplit; z0 += 4) {
+            f32x4 t4[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* src = a.qpart + (size_t)min(z0 + j, a.nsplit - 1) * a.split_stride + off;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) t4[j][db] = *reinterpret_cast<const f32x4*>(src + db * 16);
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (z0 + j < a.nsplit) {
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) acc4[db] += t4[j][db];
+                }
         }
-        const float bias = (tt >= t) ? -INFINITY : (a.pad2[(size_t)u * t + tt] ? -1e9f : 0.0f);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) sc[kb * tp + tt] = acc[kb] + bias;
+        for (int db = 0; db < 4; ++db) {
+            f32x4 q4 = acc4[db] + qb[db];
+            q4 = q4 * 0.125f;                                  // utils.py:628, after the bias (Q3)
+            if (nb * 16 + c >= K) q4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            qf[nb][db] = q4;
+        }
     }
-    __syncthreads();
 
-    for (int kb = wave; kb < K; kb += 4) {
-        float* s = sc + kb * tp;
-        float m = -INFINITY;
-        for (int tt = lane; tt < tp; tt += 64) m = fmaxf(m, s[tt]);
-        m = wave_max(m);
-        float sum = 0.f;
-        for (int tt = lane; tt < tp; tt += 64) { const float e = expf(s[tt] - m); s[tt] = e; sum += e; }
-        sum = wave_sum(sum);
-        for (int tt = lane; tt < tp; tt += 64) s[tt] = s[tt] / sum;
-    }
-    __syncthreads();
-
-    const int grp = lane >> 4, c = lane & 15;
-    f32x4 o[KB];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) o[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* kb = a.kc + ((size_t)u * a.heads + h) * t * 64;
     const float* vb = a.v + ((size_t)u * a.heads + h) * t * 64;
-    for (int tb = wave * 4; tb < t; tb += 16) {
-        const int tt = tb + grp;
-        if (tt < t) {
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (size_t)tt * 64 + c * 4);
+    const int32_t* padrow = a.pad2 + (size_t)u * t;
+    float m_run[NB], l_run[NB];
+    f32x4 o[NB][4];
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) o[kb] += vv * sc[kb * tp + tt];
+    for (int nb = 0; nb < NB; ++nb) {
+        m_run[nb] = -INFINITY; l_run[nb] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[nb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int nblk = (t + 15) >> 4;
+    f32x4 kf[4], vf[4];
+    int32_t padv[4];                                           // branch-free loads: clamped indices, masks applied at use
+    auto load_block = [&](int blk) {
+        const int key0 = blk * 16;
+        const float* kr = kb + (size_t)min(key0 + c, t - 1) * 64 + 4 * g;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) kf[db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + 4 * g + r;
+            vf[r] = *reinterpret_cast<const f32x4*>(vb + (size_t)min(key, t - 1) * 64 + 4 * c);
+            padv[r] = padrow[min(key, t - 1)];
+        }
+    };
+    if (wave < nblk) load_block(wave);
+    for (int blk = wave; blk < nblk; blk += 4) {
+        f32x4 kc4[4], vc4[4];
+        float bc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kc4[i] = kf[i]; vc4[i] = vf[i];
+            bc[i] = (blk * 16 + 4 * g + i >= t) ? -INFINITY : (padv[i] ? -1e9f : 0.0f);
+        }
+        if (blk + 4 < nblk) load_block(blk + 4);               // next block's loads fly under this block's MFMAs
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc4[db][j], qf[nb][db][j], s, 0, 0, 0);
+            // s[r] = S[beam nb*16+c][key key0 + 4g + r]
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] += bc[r]; mx = fmaxf(mx, s[r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[nb], mx);
+            const float alpha = expf(m_run[nb] - m_new);
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] = expf(s[r] - m_new); ls += s[r]; }
+            l_run[nb] = l_run[nb] * alpha + ls;
+            m_run[nb] = m_new;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[nb][j] = o[nb][j] * alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc4[r][j], s[r], o[nb][j], 0, 0, 0);
         }
     }
+    // o[nb][j][r'] = O[beam nb*16+c][d = 16g + 4r' + j] of this wave's keys (unnormalised)
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
+    for (int nb = 0; nb < NB; ++nb) {
+        float l = l_run[nb];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (g == 0) { wm[wave][nb][c] = m_run[nb]; wl[wave][nb][c] = l; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { o[kb][j] += __shfl_xor(o[kb][j], 16); o[kb][j] += __shfl_xor(o[kb][j], 32); }
-        if (grp == 0) reinterpret_cast<f32x4*>(red)[(wave * KB + kb) * 16 + c] = o[kb];
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wo[wave][nb][16 * g + 4 * r + j][c] = o[nb][j][r];
     }
     __syncthreads();
-    for (int i = tid; i < KB * 16; i += 256) {
-        const int kb = i >> 4, cc = i & 15;
-        if (kb < K) {
-            const f32x4* rp = reinterpret_cast<const f32x4*>(red);
-            const f32x4 v = (rp[(0 * KB + kb) * 16 + cc] + rp[(1 * KB + kb) * 16 + cc]) +
-                            (rp[(2 * KB + kb) * 16 + cc] + rp[(3 * KB + kb) * 16 + cc]);
-            *reinterpret_cast<f32x4*>(a.ctx + (size_t)(u * K + kb) * hidden + h * 64 + cc * 4) = v;
+    for (int i = tid; i < NB * 16 * 16; i += 256) {
+        const int beam = i >> 4, d4 = i & 15, nb = beam >> 4, bc = beam & 15;
+        if (beam < K) {
+            const float M = fmaxf(fmaxf(wm[0][nb][bc], wm[1][nb][bc]), fmaxf(wm[2][nb][bc], wm[3][nb][bc]));
+            float sc[4], L = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { sc[w] = expf(wm[w][nb][bc] - M); L += sc[w] * wl[w][nb][bc]; }
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc += sc[w] * wo[w][nb][4 * d4 + e][bc];
+                v[e] = acc / L;
+            }
+            *reinterpret_cast<f32x4*>(a.ctx + (size_t)(u * K + beam) * hidden + h * 64 + 4 * d4) = v;
         }
     }
 }
 
 int cross_kb(int k) { return k <= 1 ? 1 : k <= 2 ? 2 : k <= 4 ? 4 : k <= 8 ? 8 : k <= 12 ? 12 : k <= 16 ? 16 : 32; }
-
-template <int KB>
-hipError_t launch_cross(const CrossAttnArgs& a, size_t lds, hipStream_t s)
-{
-    auto kern = decoder_cross_attention_kernel<KB>;
-    static bool attr_done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           150 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done[dev] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(a.heads, a.b), dim3(256), lds, s, a);
-    return hipGetLastError();
-}
 
 template <int KB>
 hipError_t launch_self(const SelfAttnArgs& a, size_t lds, hipStream_t s)
@@ -431,24 +475,11 @@ hipError_t launch_decoder_self_attention(const SelfAttnArgs& a, hipStream_t s)
     }
 }
 
-size_t cross_attention_lds_bytes(int k, int tp)
-{
-    const int kb = cross_kb(k);
-    return ((size_t)kb * 64 * 5 + (size_t)kb * tp) * sizeof(float);
-}
-
 hipError_t launch_decoder_cross_attention(const CrossAttnArgs& a, hipStream_t s)
 {
     if (a.b <= 0) return hipSuccess;
-    const size_t lds = cross_attention_lds_bytes(a.k, a.tp);
-    if (lds > 150 * 1024 || a.k > ASR_MAX_BEAM) return hipErrorInvalidValue;
-    switch (cross_kb(a.k)) {
-        case 1: return launch_cross<1>(a, lds, s);
-        case 2: return launch_cross<2>(a, lds, s);
-        case 4: return launch_cross<4>(a, lds, s);
-        case 8: return launch_cross<8>(a, lds, s);
-        case 12: return launch_cross<12>(a, lds, s);
-        case 16: return launch_cross<16>(a, lds, s);
-        default: return launch_cross<32>(a, lds, s);
-    }
+    if (a.k > ASR_MAX_BEAM || a.k < 1 || a.t < 1) return hipErrorInvalidValue;
+    if (a.k <= 16) hipLaunchKernelGGL(decoder_cross_attention_kernel<1>, dim3(a.heads, a.b), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(decoder_cross_attention_kernel<2>, dim3(a.heads, a.b), dim3(256), 0, s, a);
+    return hipGetLastError();
 }

@@ -67,8 +67,7 @@ struct asr_handle {
     float *xin = nullptr, *x0 = nullptr, *x1 = nullptr, *x2 = nullptr, *x3 = nullptr, *qkv = nullptr, *hid = nullptr;
     int32_t *pad = nullptr, *pad2 = nullptr;
     double* norm_scratch = nullptr;
-    std::vector<float*> cross_kT, cross_v;
-    int cross_tp = 0;
+    std::vector<float*> cross_k, cross_v;
 
     // decoder workspaces (capacity in rows = n*K)
     int cap_dec_n = 0;
@@ -160,7 +159,7 @@ const char* gemm_class_name(int M, int N, int epilogue)
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const bool big = tiles128 >= 512;
     switch (epilogue) {
-        case EPI_GLU: return big ? "gemm_f32_nt<128,128,GLU>" : "gemm_f32_nt<64,128,GLU>";
+        case EPI_GLU: return big ? "gemm_f32_nt<128,128,GLU>" : "gemm_f32_nt<64,64,GLU>";
         case EPI_PARTIAL: return big ? "gemm_f32_nt<128,128,PARTIAL>" : "gemm_f32_nt<64,64,PARTIAL>";
         case EPI_BIAS: return big ? "gemm_f32_nt<128,128,BIAS>" : "gemm_f32_nt<64,64,BIAS>";
         default: return big ? "gemm_f32_nt<128,128,ACT>" : "gemm_f32_nt<64,64,ACT>";
@@ -283,7 +282,7 @@ int upload(asr_handle* h, const std::string& name, float** dst)
     return ASR_OK;
 }
 
-// ff_hidden first dense: GLU weights packed [2F][H] in groups of 32 rows: value rows | gate rows
+// ff_hidden first dense: GLU weights packed [2F][H] per 32 rows: 16 value rows | 16 gate rows
 int upload_ffn1(asr_handle* h, const std::string& p, float** w, float** b)
 {
     if (!h->glu) {
@@ -297,12 +296,12 @@ int upload_ffn1(asr_handle* h, const std::string& p, float** w, float** b)
     const HostTensor& b2 = h->staged.at(p + "/ff_hidden/dense/arg2/bias");
     const int F = h->F, H = h->H;
     std::vector<float> wp((size_t)2 * F * H), bp((size_t)2 * F);
-    for (int g = 0; g < F / 32; ++g)
-        for (int r = 0; r < 32; ++r) {
-            memcpy(&wp[((size_t)g * 64 + r) * H], &w1.data[((size_t)g * 32 + r) * H], (size_t)H * sizeof(float));
-            memcpy(&wp[((size_t)g * 64 + 32 + r) * H], &w2.data[((size_t)g * 32 + r) * H], (size_t)H * sizeof(float));
-            bp[(size_t)g * 64 + r] = b1.data[(size_t)g * 32 + r];
-            bp[(size_t)g * 64 + 32 + r] = b2.data[(size_t)g * 32 + r];
+    for (int g = 0; g < F / 16; ++g)
+        for (int r = 0; r < 16; ++r) {
+            memcpy(&wp[((size_t)g * 32 + r) * H], &w1.data[((size_t)g * 16 + r) * H], (size_t)H * sizeof(float));
+            memcpy(&wp[((size_t)g * 32 + 16 + r) * H], &w2.data[((size_t)g * 16 + r) * H], (size_t)H * sizeof(float));
+            bp[(size_t)g * 32 + r] = b1.data[(size_t)g * 16 + r];
+            bp[(size_t)g * 32 + 16 + r] = b2.data[(size_t)g * 16 + r];
         }
     int rc = dev_alloc_t(h, w, wp.size());
     if (rc) return rc;
@@ -317,19 +316,17 @@ int upload_ffn1(asr_handle* h, const std::string& p, float** w, float** b)
 int ensure_encoder_capacity(asr_handle* h, int n, int t)
 {
     const size_t rows = (size_t)n * t;
-    const int tp = (t + 63) / 64 * 64;
-    if (rows <= h->cap_rows && n <= h->cap_n && tp <= h->cross_tp) return ASR_OK;
+    if (rows <= h->cap_rows && n <= h->cap_n) return ASR_OK;
     const size_t nrows = std::max(rows, h->cap_rows);
-    const int nn = std::max(n, h->cap_n), ntp = std::max(tp, h->cross_tp);
+    const int nn = std::max(n, h->cap_n);
     float** bufs[] = {&h->xin, &h->x0, &h->x1, &h->x2, &h->x3, &h->qkv, &h->hid};
     for (auto b : bufs) { dev_free(h, *b); *b = nullptr; }
     dev_free(h, h->pad); dev_free(h, h->pad2); dev_free(h, h->norm_scratch);
     h->pad = h->pad2 = nullptr; h->norm_scratch = nullptr;
-    for (auto p : h->cross_kT) dev_free(h, p);
+    for (auto p : h->cross_k) dev_free(h, p);
     for (auto p : h->cross_v) dev_free(h, p);
-    h->cross_kT.assign(h->L, nullptr);
+    h->cross_k.assign(h->L, nullptr);
     h->cross_v.assign(h->L, nullptr);
-    // rows capacity must also cover nn * ntp-ish packing of cross K/V: size those by nn*ntp
     const size_t H = h->H;
     int rc = 0;
     rc |= dev_alloc_t(h, &h->xin, nrows * (size_t)h->D);
@@ -342,13 +339,12 @@ int ensure_encoder_capacity(asr_handle* h, int n, int t)
     rc |= dev_alloc_t(h, &h->pad, nrows);
     rc |= dev_alloc_t(h, &h->pad2, nrows);
     rc |= dev_alloc_t(h, &h->norm_scratch, input_norm_scratch_doubles(nn, 0, 0));
-    const size_t cross_elems = std::max(nrows, (size_t)nn * ntp) * H + (size_t)nn * 64 * H;   // kT rows padded to tp
     for (int l = 0; l < h->L && !rc; ++l) {
-        rc |= dev_alloc_t(h, &h->cross_kT[l], cross_elems);
+        rc |= dev_alloc_t(h, &h->cross_k[l], nrows * H);
         rc |= dev_alloc_t(h, &h->cross_v[l], nrows * H);
     }
     if (rc) return ASR_ERR_HIP;
-    h->cap_rows = nrows; h->cap_n = nn; h->cross_tp = ntp;
+    h->cap_rows = nrows; h->cap_n = nn;
     return ASR_OK;
 }
 
@@ -458,12 +454,11 @@ int run_encoder(asr_handle* h, const float* X_dev, int n, int t)
 int run_cross_kv(asr_handle* h, int n, int t)
 {
     const int M = n * t, H = h->H;
-    const int tp = (t + 63) / 64 * 64;
     for (int l = 0; l < h->L; ++l) {
         int rc = gemm(h, h->x0, h->dec[l].wkv, h->dec[l].bkv, h->qkv, M, 2 * H, H, EPI_BIAS, 1);   // utils.py:618
         if (rc) return rc;
         ProfScope ps(h, "pack_cross_kv", 0, 4.0 * M * 4.0 * H);
-        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, tp, h->heads, h->cross_kT[l], h->cross_v[l], h->stream));
+        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, h->heads, h->cross_k[l], h->cross_v[l], h->stream));
     }
     return ASR_OK;
 }
@@ -472,7 +467,6 @@ int run_cross_kv(asr_handle* h, int n, int t)
 int run_decode_step(asr_handle* h, int n, int t)
 {
     const int R = n * h->K, H = h->H, F = h->F, K = h->K;
-    const int tp = (t + 63) / 64 * 64;
     hipStream_t s = h->stream;
     const BeamState& st = h->beam;
     int s_qkv, s_proj, s_ffn2;
@@ -509,8 +503,8 @@ int run_decode_step(asr_handle* h, int n, int t)
         {
             CrossAttnArgs a{};
             a.qpart = h->part; a.nsplit = s_proj; a.split_stride = RH; a.qbias = b.bq;
-            a.kT = h->cross_kT[l]; a.v = h->cross_v[l]; a.pad2 = h->pad2; a.done = st.done;
-            a.ctx = h->dctx; a.b = n; a.k = K; a.heads = h->heads; a.t = t; a.tp = tp;
+            a.kc = h->cross_k[l]; a.v = h->cross_v[l]; a.pad2 = h->pad2; a.done = st.done;
+            a.ctx = h->dctx; a.b = n; a.k = K; a.heads = h->heads; a.t = t;
             ProfScope ps(h, "decoder_cross_attention", 4.0 * R * (double)t * H, 4.0 * 2.0 * n * (double)t * H);
             HIP_TRY(h, launch_decoder_cross_attention(a, s));
         }
@@ -629,8 +623,6 @@ int check_xshape(asr_handle* h, int n, int t, int d)
 {
     if (n < 0 || t < 0 || d != h->D) return fail(h, ASR_ERR_ARG, "X must be [n, t, input_dim=" + std::to_string(h->D) + "]");
     if (n > 0 && t < 1) return fail(h, ASR_ERR_ARG, "t must be >= 1");
-    if ((size_t)((t + 63) / 64 * 64) * h->K * 4 + (size_t)h->K * 64 * 5 * 4 + 4096 > 150 * 1024)
-        return fail(h, ASR_ERR_ARG, "t * beam_size exceeds the cross-attention LDS budget");
     if (self_attention_lds_bytes(h->K, std::min(t + 50, (int)h->cfg.max_target_length) + 2) > 150 * 1024)
         return fail(h, ASR_ERR_ARG, "min(t + 50, max_target_length) * beam_size exceeds the self-attention LDS budget");
     return ASR_OK;
@@ -715,7 +707,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->done_host), (size_t)(cfg->max_target_length + 8) * sizeof(int32_t), 0)) != hipSuccess)
         return hip_fail(e, "hipHostMalloc");
-    h->cross_kT.assign(h->L, nullptr); h->cross_v.assign(h->L, nullptr);
+    h->cross_k.assign(h->L, nullptr); h->cross_v.assign(h->L, nullptr);
     h->kcache.assign(h->L, nullptr); h->vcache.assign(h->L, nullptr);
     *out = h;
     return ASR_OK;
@@ -949,17 +941,17 @@ int asr_op_dense(asr_handle* h, const float* x, const float* w, const float* bia
 int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int32_t m,
                      int32_t n, int32_t k, float* y)
 {
-    if (!h || !x || !w1 || !w2 || !y || m < 1 || n < 32 || (n & 31) || k < 4 || (k & 3))
-        return h ? fail(h, ASR_ERR_ARG, "bad argument (n must be a multiple of 32)") : ASR_ERR_ARG;
+    if (!h || !x || !w1 || !w2 || !y || m < 1 || n < 16 || (n & 15) || k < 4 || (k & 3))
+        return h ? fail(h, ASR_ERR_ARG, "bad argument (n must be a multiple of 16)") : ASR_ERR_ARG;
     int rc = set_device(h);
     if (rc) return rc;
     std::vector<float> wp((size_t)2 * n * k), bp((size_t)2 * n, 0.f);
-    for (int g = 0; g < n / 32; ++g)
-        for (int r = 0; r < 32; ++r) {
-            memcpy(&wp[((size_t)g * 64 + r) * k], &w1[((size_t)g * 32 + r) * k], (size_t)k * 4);
-            memcpy(&wp[((size_t)g * 64 + 32 + r) * k], &w2[((size_t)g * 32 + r) * k], (size_t)k * 4);
-            if (b1) bp[(size_t)g * 64 + r] = b1[(size_t)g * 32 + r];
-            if (b2) bp[(size_t)g * 64 + 32 + r] = b2[(size_t)g * 32 + r];
+    for (int g = 0; g < n / 16; ++g)
+        for (int r = 0; r < 16; ++r) {
+            memcpy(&wp[((size_t)g * 32 + r) * k], &w1[((size_t)g * 16 + r) * k], (size_t)k * 4);
+            memcpy(&wp[((size_t)g * 32 + 16 + r) * k], &w2[((size_t)g * 16 + r) * k], (size_t)k * 4);
+            if (b1) bp[(size_t)g * 32 + r] = b1[(size_t)g * 16 + r];
+            if (b2) bp[(size_t)g * 32 + 16 + r] = b2[(size_t)g * 16 + r];
         }
     TmpBufs tb;
     float *dx, *dw, *db, *dy;

@@ -10,20 +10,29 @@
 // 2q+1: the MFMA k index is only a summation label, so any A/B-consistent assignment is valid).
 // LDS image: [rows][8 chunks of 16 B] with the chunk XOR-swizzled by (row & 7).
 #include "asr_common.h"
+#include <math.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int BK = 32;   // k-depth of one LDS stage (floats)
+bool g_force_reg_stage = false;   // development / test switch (asr_gemm_force_reg_stage)
+#ifndef ASR_GEMM_DEBUG
+#define ASR_GEMM_DEBUG 0   // development only: 1 = no global loads in the loop, 2 = no LDS stores, 4 = no barrier
+#endif
+
+typedef __attribute__((address_space(3))) void* LdsPtr;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+// DMA = true: tiles are staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no
+// ds_write); needs K % 32 == 0.  DMA = false: register-staged path for any K % 4 == 0.
+template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
 __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
 {
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    static_assert(EPI != EPI_GLU || (NI % 2) == 0, "GLU pairs 32-column fragments");
     constexpr int A_LD = BM / 32, B_LD = BN / 32;      // 16-B loads per thread per stage
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -63,90 +72,181 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, 
             for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.0f;
 
     const int lrow = tid >> 3, lch = tid & 7;
-    f32x4 ra[A_LD], rb[B_LD];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // Software pipeline: two register sets hold the global loads of the next two k-tiles (set = tile
+    // parity), two LDS buffers hold the current and the next tile, and the A/B fragments of k-chunk q+1
+    // are read from LDS before the MFMAs of chunk q are issued.  The LDS stores of tile kt+1 are issued in
+    // front of the MFMAs of chunk 2, the barrier and the first fragment read of tile kt+1 in front of the
+    // MFMAs of chunk 3: no LDS latency sits between two MFMA groups (two waves of a SIMD run in phase, so
+    // a bubble in one is a bubble in both - measured with tools/mfma_probe.hip).
+    const float* arow[A_LD];
+    const float* brow[B_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) arow[i] = p.A + (size_t)min(m0 + lrow + 32 * i, p.M - 1) * p.lda;
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) brow[i] = p.W + (size_t)min(n0 + lrow + 32 * i, p.N - 1) * p.ldw;
 
-    auto gload = [&](int k0) {
+    f32x4 ra[2][A_LD], rb[2][B_LD];
+    bool kvalid[2] = {false, false};
+    // Branch-free loads (so that the compiler can count outstanding loads per register set): rows past
+    // M / N are clamped to the last row (their products land in C rows / columns that are never stored)
+    // and a k-chunk past kend is loaded from k = kbeg and zeroed on its way into LDS.
+    auto gload = [&](auto setc, int k0) {
+        constexpr int S = decltype(setc)::value;
         const int kk = k0 + lch * 4;
         const bool kok = kk < kend;
+        const int kc = kok ? kk : kbeg;
+        kvalid[S] = kok;
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int gm = m0 + lrow + 32 * i;
-            ra[i] = (kok && gm < p.M) ? *reinterpret_cast<const f32x4*>(p.A + (size_t)gm * p.lda + kk) : zero4;
-        }
+        for (int i = 0; i < A_LD; ++i) ra[S][i] = *reinterpret_cast<const f32x4*>(arow[i] + kc);
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int gn = n0 + lrow + 32 * i;
-            rb[i] = (kok && gn < p.N) ? *reinterpret_cast<const f32x4*>(p.W + (size_t)gn * p.ldw + kk) : zero4;
-        }
+        for (int i = 0; i < B_LD; ++i) rb[S][i] = *reinterpret_cast<const f32x4*>(brow[i] + kc);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](auto setc, int buf) {
+        constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int row = lrow + 32 * i;
-            As[(buf * BM + row) * 8 + (lch ^ (row & 7))] = ra[i];
+            As[(buf * BM + row) * 8 + (lch ^ (row & 7))] = kvalid[S] ? ra[S][i] : zero4;
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const int row = lrow + 32 * i;
-            Bs[(buf * BN + row) * 8 + (lch ^ (row & 7))] = rb[i];
+            Bs[(buf * BN + row) * 8 + (lch ^ (row & 7))] = kvalid[S] ? rb[S][i] : zero4;
         }
     };
-
-    if (nk > 0) {
-        gload(kbeg);
-        lstore(0);
-    }
-    __syncthreads();
 
     const int l31 = lane & 31, lhalf = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+    f32x4 af[2][MI], bf[2][NI];
+    auto fload = [&](auto slotc, int buf, int q) {
+        constexpr int S = decltype(slotc)::value;
+        const int ch = 2 * q + lhalf;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ch = 2 * q + lhalf;
-            f32x4 af[MI], bf[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int row = wm0 + i * 32 + l31;
-                af[i] = As[(buf * BM + row) * 8 + (ch ^ (row & 7))];
-            }
-#pragma unroll
-            for (int n = 0; n < NI; ++n) {
-                const int row = wn0 + n * 32 + l31;
-                bf[n] = Bs[(buf * BN + row) * 8 + (ch ^ (row & 7))];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int n = 0; n < NI; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[n][j], acc[i][n], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm0 + i * 32 + l31;
+            af[S][i] = As[(buf * BM + row) * 8 + (ch ^ (row & 7))];
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const int row = wn0 + n * 32 + l31;
+            bf[S][n] = Bs[(buf * BN + row) * 8 + (ch ^ (row & 7))];
+        }
+    };
+    auto mma = [&](auto slotc) {
+        constexpr int S = decltype(slotc)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NI; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[S][i][j], bf[S][n][j], acc[i][n], 0, 0, 0);
+    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+
+    if constexpr (DMA) {
+        // One glds wave-instruction fills 8 rows x 128 B of the LDS image, lane-linear: lane l lands on
+        // chunk position l&7 of row l>>3, so it fetches the source chunk (l&7)^(l>>3) - the XOR swizzle
+        // is applied on the global address.  Tiles past the K range re-read tile 0 (never consumed).
+        [[maybe_unused]] const int src_ch = ((lane & 7) ^ (lane >> 3)) * 4;
+        auto glds = [&](int buf, int k0) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the kernel's stub; it cannot parse the LDS address-space cast)
+            const int kc = (k0 < kend ? k0 : kbeg) + src_ch;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i)
+                __builtin_amdgcn_global_load_lds(arow[i] + kc, (LdsPtr)(As + (buf * BM + 32 * i + wave * 8) * 8), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)
+                __builtin_amdgcn_global_load_lds(brow[i] + kc, (LdsPtr)(Bs + (buf * BN + 32 * i + wave * 8) * 8), 16, 0, 0);
+#endif
+        };
+        if (nk > 0) {
+            glds(0, kbeg);
+            __syncthreads();                     // drains the DMA (vmcnt) and publishes the tile
+            glds(1, kbeg + BK);
+            fload(c0{}, 0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int buf = kt & 1;
+                fload(c1{}, buf, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(c0{});
+                __builtin_amdgcn_sched_barrier(0);
+                fload(c0{}, buf, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(c1{});
+                __builtin_amdgcn_sched_barrier(0);
+                fload(c1{}, buf, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(c0{});
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                 // tile kt+1 has landed; every wave holds its last fragments of tile kt
+                fload(c0{}, buf ^ 1, 0);
+                glds(buf, kbeg + (kt + 2) * BK); // refill the buffer just released
+                __builtin_amdgcn_sched_barrier(0);
+                mma(c1{});
+            }
+        }
+    } else {
+        // one k-tile; SET = register set that holds tile kt+1 (the other set holds tile kt+2, in flight)
+        auto ktile = [&](auto setc, int kt) {
+            constexpr int S = decltype(setc)::value;
+            const int buf = kt & 1;
+            fload(c1{}, buf, 1);
+            __builtin_amdgcn_sched_barrier(0);     // fragment reads of chunk q+1 stay in front of the MFMAs of chunk q
+            mma(c0{});
+            __builtin_amdgcn_sched_barrier(0);
+            fload(c0{}, buf, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(c1{});
+            __builtin_amdgcn_sched_barrier(0);
+            fload(c1{}, buf, 3);
+            if (!(ASR_GEMM_DEBUG & 2)) lstore(std::integral_constant<int, S>{}, buf ^ 1);   // LDS stores of tile kt+1 complete under the MFMAs of chunk 2
+            __builtin_amdgcn_sched_barrier(0);
+            mma(c0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ASR_GEMM_DEBUG & 4)) __syncthreads();
+            fload(c0{}, buf ^ 1, 0);
+            if (!(ASR_GEMM_DEBUG & 1)) gload(std::integral_constant<int, S>{}, kbeg + (kt + 3) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(c1{});
+        };
+
+        // Every step is unconditional (tiles past the K range load a clamped address and are stored to LDS as
+        // zeros), so the number of outstanding loads is static and the waits are exact; an odd tile count
+        // costs one all-zero tile.
+        if (nk > 0) {
+            gload(c0{}, kbeg);
+            gload(c1{}, kbeg + BK);
+            lstore(c0{}, 0);
+            __syncthreads();
+            gload(c0{}, kbeg + 2 * BK);
+            fload(c0{}, 0, 0);
+            for (int kt = 0; kt < nk; kt += 2) {
+                ktile(c1{}, kt);
+                ktile(c0{}, kt + 1);
+            }
+        }
     }
 
     // ---- epilogue: acc reg r of lane l is C[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31] of its 32x32 fragment
     if constexpr (EPI == EPI_GLU) {
+        // W rows are packed in groups of 32: 16 value rows | 16 gate rows, so every 32-column fragment
+        // holds its own pairs: lanes 0-15 the value, lanes 16-31 the gate of the same 16 output columns.
         const int nout = p.N >> 1;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int n = 0; n < NI; n += 2) {
-                const int pcol = n0 + wn0 + n * 32 + l31;            // packed column of the value half
-                const int col = ((n0 + wn0) >> 1) + (n >> 1) * 32 + l31;
-                if (col < nout) {
-                    const float b1 = p.bias ? p.bias[pcol] : 0.f;
-                    const float b2 = p.bias ? p.bias[pcol + 32] : 0.f;
+            for (int n = 0; n < NI; ++n) {
+                const int pcol = n0 + wn0 + n * 32 + l31;            // packed column
+                const int col = ((n0 + wn0 + n * 32) >> 1) + (l31 & 15);
+                const float bb = (p.bias && pcol < p.N) ? p.bias[pcol] : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int gm = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                        if (gm < p.M)
-                            p.C[(size_t)gm * p.ldc + col] = (acc[i][n][r] + b1) * sigmoidf_(acc[i][n + 1][r] + b2);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const float mine = acc[i][n][r] + bb;
+                    const float gate = __shfl_down(mine, 16);
+                    const int gm = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    if (l31 < 16 && col < nout && gm < p.M) p.C[(size_t)gm * p.ldc + col] = mine * sigmoidf_(gate);
                 }
             }
     } else {
@@ -177,15 +277,15 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
-hipError_t launch_tile(const GemmArgs& a, hipStream_t s)
+template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
+hipError_t launch_tile_impl(const GemmArgs& a, hipStream_t s)
 {
     const int nt_m = (a.M + BM - 1) / BM, nt_n = (a.N + BN - 1) / BN;
     const int split = a.split_k < 1 ? 1 : a.split_k;
     int kchunk = (a.K + split - 1) / split;
     kchunk = (kchunk + BK - 1) / BK * BK;
     const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(f32x4);
-    auto kern = gemm_f32_nt_kernel<BM, BN, WM, WN, EPI>;
+    auto kern = gemm_f32_nt_kernel<BM, BN, WM, WN, EPI, DMA>;
     static bool attr_done[64] = {};   // per instantiation, per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -200,30 +300,46 @@ hipError_t launch_tile(const GemmArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+template <int BM, int BN, int WM, int WN, int EPI>
+hipError_t launch_tile(const GemmArgs& a, hipStream_t s)
+{
+    // the DMA-staged loop measures +2.5 % on 128x128 tiles and -5 % on the smaller ones
+    const bool dma = BM == 128 && BN == 128 && (a.K % BK) == 0 && ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) & 15) == 0 && !g_force_reg_stage;
+    return dma ? launch_tile_impl<BM, BN, WM, WN, EPI, true>(a, s) : launch_tile_impl<BM, BN, WM, WN, EPI, false>(a, s);
+}
+
 template <int EPI>
 hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s)
 {
     switch (tile) {
         case 1: return launch_tile<128, 128, 64, 64, EPI>(a, s);
         case 3: return launch_tile<64, 128, 32, 64, EPI>(a, s);
-        case 4:
-            if constexpr (EPI == EPI_GLU) return launch_tile<64, 128, 32, 64, EPI>(a, s);
-            else return launch_tile<128, 64, 64, 32, EPI>(a, s);
-        default:
-            if constexpr (EPI == EPI_GLU) return launch_tile<64, 128, 32, 64, EPI>(a, s);
-            else return launch_tile<64, 64, 32, 32, EPI>(a, s);
+        case 4: return launch_tile<128, 64, 64, 32, EPI>(a, s);
+        default: return launch_tile<64, 64, 32, 32, EPI>(a, s);
     }
 }
 
 }  // namespace
 
+void gemm_force_reg_stage(bool on) { g_force_reg_stage = on; }
+
 int gemm_pick_split_k(int M, int N, int K)
 {
-    // decode-time projections (M = batch*beam rows): 64x64 tiles; split K until >= ~2 workgroups per CU
-    const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    int split = 1;
-    while (tiles * split < 512 && split < ASR_MAX_SPLITK && K / (split * 2) >= 128) split *= 2;
-    return split;
+    // Decode-time projections (M = batch*beam rows) run 64x64 tiles, 4 waves each.  The f32 MFMA pipe is
+    // the bound, so what matters is how evenly the waves fill the 1024 SIMDs: w waves per SIMD cost
+    // ceil(w) turns of (K / split) / 32 k-tiles (0.45 us each); every extra slab costs one more write +
+    // read of M x N floats.  Constants fitted to tools/gemm_bench.hip on MI355X.
+    const double tiles = (double)((M + 63) / 64) * ((N + 63) / 64);
+    const double w1 = tiles * 4.0 / 1024.0;
+    int best = 1;
+    double best_t = 1e30;
+    for (int split = 1; split <= ASR_MAX_SPLITK; split *= 2) {
+        if (split > 1 && K / split < 128) break;
+        const double ktiles = ceil((double)K / split / 32.0);
+        const double t = ceil(w1 * split - 1e-9) * ktiles * 0.45 + split * (double)M * N * 4.0 / 4.0e6;
+        if (t < best_t - 1e-9) { best_t = t; best = split; }
+    }
+    return best;
 }
 
 hipError_t launch_gemm_f32(const GemmArgs& a, int tile_hint, hipStream_t s)
@@ -231,13 +347,11 @@ hipError_t launch_gemm_f32(const GemmArgs& a, int tile_hint, hipStream_t s)
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if ((a.K & 3) || (a.lda & 3) || (a.ldw & 3)) return hipErrorInvalidValue;
     if (a.split_k > 1 && a.epilogue != EPI_PARTIAL) return hipErrorInvalidValue;
-    if (a.epilogue == EPI_GLU && (a.N & 63)) return hipErrorInvalidValue;
+    if (a.epilogue == EPI_GLU && (a.N & 31)) return hipErrorInvalidValue;
     int tile = tile_hint;
     if (tile == 0) {
         const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-        if (tiles128 >= 512) tile = 1;                          // encoder-sized: 128x128
-        else if (a.epilogue == EPI_GLU) tile = 3;
-        else tile = 2;
+        tile = tiles128 >= 512 ? 1 : 2;                         // encoder-sized: 128x128, decode rows: 64x64
     }
     switch (a.epilogue) {
         case EPI_BIAS: return launch_epi<EPI_BIAS>(a, tile, s);

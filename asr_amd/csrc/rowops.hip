@@ -194,6 +194,89 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* __rest
     }
 }
 
+// Same operation for the decode-time row counts (a few hundred rows): one 256-thread workgroup per row so
+// that the launch covers the chip, and the split-K slabs are fetched four at a time (independent loads in
+// flight) but still summed in slab order.
+template <int NCH>   // 16-byte chunks per thread: hidden <= NCH*1024
+__global__ __launch_bounds__(256) void add_layer_norm_row_kernel(const float* __restrict__ resid, const float* __restrict__ part,
+                                                                  int nsplit, size_t split_stride, const float* __restrict__ dbias,
+                                                                  const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                  const int32_t* __restrict__ mask, int32_t* __restrict__ pad2_out,
+                                                                  int hidden, float* __restrict__ y, const int32_t* __restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ float red[3][4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h4 = hidden >> 2;
+    const size_t base = (size_t)row * hidden;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = tid + 256 * c;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (ch < h4) {
+            a = reinterpret_cast<const f32x4*>(resid + base)[ch];
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            for (int z0 = 0; z0 < nsplit; z0 += 4) {
+                f32x4 t4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int z = min(z0 + j, nsplit - 1);
+                    t4[j] = reinterpret_cast<const f32x4*>(part + z * split_stride + base)[ch];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (z0 + j < nsplit) d += t4[j];
+            }
+            if (dbias) d += reinterpret_cast<const f32x4*>(dbias)[ch];
+            a += d;
+            s += (a[0] + a[1]) + (a[2] + a[3]);
+        }
+        v[c] = a;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)hidden;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (tid + 256 * c < h4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float dlt = v[c][j] - mean; q += dlt * dlt; }
+        }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[1][wave] = q;
+    __syncthreads();
+    const float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)hidden;
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    const bool zero_row = mask && mask[row];
+    float asum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = tid + 256 * c;
+        if (ch < h4) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(scale)[ch], b = reinterpret_cast<const f32x4*>(bias)[ch];
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = ((v[c][j] - mean) * rstd) * g[j] + b[j];
+                if (zero_row) o[j] = o[j] * 0.0f;
+                asum += fabsf(o[j]);
+            }
+            reinterpret_cast<f32x4*>(y + base)[ch] = o;
+        }
+    }
+    if (pad2_out) {
+        asum = wave_sum(asum);
+        if (lane == 0) red[2][wave] = asum;
+        __syncthreads();
+        if (tid == 0) pad2_out[row] = (((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) == 0.0f) ? 1 : 0;
+    }
+}
+
 // ---- embedding * sqrt(H) + timing signal of the current position (model.py:569-576) ------------
 __global__ __launch_bounds__(256) void embed_pe_kernel(const float* __restrict__ E, const int32_t* __restrict__ preds0,
                                                         const int32_t* __restrict__ preds1, int preds_stride,
@@ -216,30 +299,21 @@ __global__ __launch_bounds__(256) void embed_pe_kernel(const float* __restrict__
     }
 }
 
-// ---- cross-attention K/V layouts: kv [n*t][2H] -> kT [n][heads][64][tp], v [n][heads][t][64] ----
-__global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restrict__ kv, int t, int tp, int heads,
-                                                             float* __restrict__ kT, float* __restrict__ vout)
+// ---- cross-attention K/V layouts: kv [n*t][2H] -> k, v [n][heads][t][64] (head-major, so that one
+// (utterance, head) workgroup of the decode-time cross-attention streams two contiguous arrays) ----
+__global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restrict__ kv, int t, int heads,
+                                                             float* __restrict__ kout, float* __restrict__ vout)
 {
-    __shared__ float tile[64][65];
     const int t0 = blockIdx.x * 64, h = blockIdx.y, u = blockIdx.z;
     const int hidden = heads * 64;
-    const int tid = threadIdx.x;
-    // load K tile [64 t][64 d] (coalesced over d) and copy V
-    for (int i = tid; i < 64 * 16; i += 256) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
         const int tt = i >> 4, c = i & 15;
-        f32x4 k4 = {0.f, 0.f, 0.f, 0.f};
         if (t0 + tt < t) {
             const float* row = kv + ((size_t)u * t + t0 + tt) * (2 * hidden);
-            k4 = reinterpret_cast<const f32x4*>(row + h * 64)[c];
-            const f32x4 v4 = reinterpret_cast<const f32x4*>(row + hidden + h * 64)[c];
-            reinterpret_cast<f32x4*>(vout + (((size_t)u * heads + h) * t + t0 + tt) * 64)[c] = v4;
+            const size_t o = (((size_t)u * heads + h) * t + t0 + tt) * 64;
+            reinterpret_cast<f32x4*>(kout + o)[c] = reinterpret_cast<const f32x4*>(row + h * 64)[c];
+            reinterpret_cast<f32x4*>(vout + o)[c] = reinterpret_cast<const f32x4*>(row + hidden + h * 64)[c];
         }
-        tile[tt][c * 4 + 0] = k4[0]; tile[tt][c * 4 + 1] = k4[1]; tile[tt][c * 4 + 2] = k4[2]; tile[tt][c * 4 + 3] = k4[3];
-    }
-    __syncthreads();
-    for (int i = tid; i < 64 * 64; i += 256) {
-        const int d = i >> 6, tt = i & 63;
-        if (t0 + tt < tp) kT[(((size_t)u * heads + h) * 64 + d) * tp + t0 + tt] = tile[tt][d];
     }
 }
 
@@ -437,6 +511,15 @@ hipError_t launch_add_layer_norm_done(const float* resid, const float* part, int
 {
     if (rows <= 0) return hipSuccess;
     if ((hidden & 3) || hidden > 2048) return hipErrorInvalidValue;
+    if (rows <= 4096) {                                      // decode-time rows: one workgroup per row
+        if (hidden <= 1024)
+            hipLaunchKernelGGL(add_layer_norm_row_kernel<1>, dim3(rows), dim3(256), 0, s, resid, part, nsplit, split_stride, dbias,
+                               scale, bias, mask, pad2_out, hidden, y, done);
+        else
+            hipLaunchKernelGGL(add_layer_norm_row_kernel<2>, dim3(rows), dim3(256), 0, s, resid, part, nsplit, split_stride, dbias,
+                               scale, bias, mask, pad2_out, hidden, y, done);
+        return hipGetLastError();
+    }
     dim3 grid((rows + 3) / 4), block(256);
 #define ALN(N) hipLaunchKernelGGL(add_layer_norm_kernel<N>, grid, block, 0, s, resid, part, nsplit, split_stride, dbias, \
                                   scale, bias, mask, pad2_out, rows, hidden, y, done)
@@ -465,10 +548,10 @@ hipError_t launch_embed_pe(const float* E, const int32_t* preds0, const int32_t*
     return hipGetLastError();
 }
 
-hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int tp, int heads, float* kT, float* v, hipStream_t s)
+hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, float* k, float* v, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_cross_kv_kernel, dim3((tp + 63) / 64, heads, n), dim3(256), 0, s, kv, t, tp, heads, kT, v);
+    hipLaunchKernelGGL(pack_cross_kv_kernel, dim3((t + 63) / 64, heads, n), dim3(256), 0, s, kv, t, heads, k, v);
     return hipGetLastError();
 }
 
