@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libasr_amd.so')
 
 ASR_OK = 0
 FF_ACTIVATIONS = {'relu': 0, 'glu': 1, 'sigmoid': 2, 'tanh': 3, 'swish': 4}
+PRECISIONS = {'f32': 0, 'f32_bf16x6': 1, 'bf16x3': 2, 'bf16': 3}
 
 
 class AsrError(RuntimeError):
@@ -27,7 +28,7 @@ class asr_config(C.Structure):
                 ('num_blocks', C.c_int32), ('dst_vocab_size', C.c_int32), ('ff_activation', C.c_int32),
                 ('scale_embedding', C.c_int32), ('tie_embedding_and_softmax', C.c_int32),
                 ('beam_size', C.c_int32), ('max_target_length', C.c_int32), ('lp_alpha', C.c_float),
-                ('device', C.c_int32), ('reserved', C.c_int32 * 4)]
+                ('device', C.c_int32), ('precision', C.c_int32), ('reserved', C.c_int32 * 3)]
 
 
 def _preload_torch_hip_runtime():

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libasr_amd.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #define ASR_D_HEAD 64          // hidden_units / num_heads of every reference config
@@ -21,6 +22,7 @@ enum GemmEpilogue {
 struct GemmArgs {
     const float* A;    // [M, K] row-major, leading dimension lda
     const float* W;    // [N, K] row-major ("kernel [out, in]", utils.py:551), leading dimension ldw
+    const uint16_t* Wp; // gemm_split.hip only: the same matrix as bf16 planes [planes][N][K] (W unused)
     const float* bias; // [N] or null
     float* C;          // [M, ldc] (EPI_PARTIAL: [split_k][M][ldc])
     int M, N, K;
@@ -31,9 +33,15 @@ struct GemmArgs {
 // tile_hint: 0 = choose from the shape, 1 = 128x128, 2 = 64x64, 3 = 64x128(M x N), 4 = 128x64
 hipError_t launch_gemm_f32(const GemmArgs& a, int tile_hint, hipStream_t s);
 // number of K-slices the decode-time projections should use for this shape (fills the chip)
-int gemm_pick_split_k(int M, int N, int K);
+int gemm_pick_split_k(int M, int N, int K, int nprod);
 // true: always use the register-staged main loop (the DMA-staged loop needs K % 32 == 0 and is the default when it applies)
 void gemm_force_reg_stage(bool on);
+
+// f32 GEMM on the bf16 matrix cores by operand splitting (gemm_split.hip); nprod = 6 (f32 accuracy), 3 or 1 (bf16).
+// Needs K % 32 == 0 and a.Wp = bf16 planes made by gemm_split_weights_host (gemm_split_planes(nprod) of them).
+hipError_t launch_gemm_split(const GemmArgs& a, int nprod, int tile_hint, hipStream_t s);
+int gemm_split_planes(int nprod);
+void gemm_split_weights_host(const float* w, size_t count, int nplanes, uint16_t* planes);
 
 // ---- row kernels (rowops.hip) ----------------------------------------------------------------
 hipError_t launch_frame_stack_lens(const float* raw, const int32_t* lens, int n, int raw_frames, int raw_dim, int left,
@@ -68,6 +76,9 @@ struct BeamState {       // device pointers; double-buffered arrays are indexed 
     int32_t* finished[2];      // [R]
     int32_t* preds[2];         // [R, width]
     int32_t* anc[2];           // [R, width] slot (0..K-1) holding position j of row r's history
+    int32_t* live;             // [B][K*width] (position << 5 | slot) of every cache row some beam of the utterance still
+                               // descends from, positions 0 .. *pos-1, ordered by position then slot
+    int32_t* live_cnt;         // [B] entries in live
     int32_t* pos;              // [1] decode steps done so far (= position of the token fed next)
     int32_t* done;             // [1] loop has ended
     int32_t* unfinished;       // [1] scratch counter
@@ -95,6 +106,8 @@ struct SelfAttnArgs {
     float* vcache;
     const int32_t* anc0;   // BeamState.anc[0], anc[1]
     const int32_t* anc1;
+    const int32_t* live;   // BeamState.live, live_cnt
+    const int32_t* live_cnt;
     const int32_t* pos;
     const int32_t* done;
     float* ctx;            // [R, hidden]

@@ -139,61 +139,61 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
 
 // ------------------------------------------------------------------------------------------------
 // Decoder self-attention at position `pos` (model.py:588-600 with reserve_last; no mask).
-// One workgroup per (utterance, head) serves all K beams.  The beams' own k/v of position `pos`
-// are appended to the cache (slot = beam index); history position j < pos of beam b is read from
-// slot anc[b][j] (see beam_step_kernel).  Beams of one utterance share most of their history, so
-// the K loads of a 16-lane group (one history position, all beams) mostly repeat one 256-B row and
-// are served by the CU's L1: HBM/L2 traffic is the number of DISTINCT (position, slot) rows.
-// A 16-lane group covers one 64-float row with 16-B loads; the KB loads of a position are issued
-// together (memory-level parallelism instead of one dependent load per pass).
+// One workgroup per (utterance, head) serves all beams.  The beams' own k/v of position `pos` are
+// appended to the cache (slot = beam index); history position j < pos of beam b lives in slot
+// anc[b][j].  Beams of one utterance share most of their history, so beam_step_kernel keeps, per
+// utterance, the list of LIVE (position, slot) rows - rows referenced by at least one beam - and this
+// kernel streams exactly those rows once, flash-style on the exact-f32 16x16x4 MFMA (same operand
+// mapping as the cross-attention kernel below): S^T[key][beam] for all beams at once, entries whose
+// key is not on that beam's ancestry are masked to -inf.  HBM traffic = live rows, not beams x pos.
+// The new position's K keys (one per beam, valid for that beam only) are taken from LDS.
 // ------------------------------------------------------------------------------------------------
-template <int KB>
+template <int NB>
 __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArgs a)
 {
     if (*a.done) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int BEAMS = NB * 16;
     const int h = blockIdx.x, u = blockIdx.y;
     const int K = a.k, hidden = a.heads * 64, width = a.width, ls = a.lds_stride;
     const int pos = *a.pos;
-    float* qs = reinterpret_cast<float*>(smem_raw);        // [KB][64]
-    float* vnew = qs + KB * 64;                            // [KB][64]
-    float* red = vnew + KB * 64;                           // [4][KB][64]
-    float* sc = red + 4 * KB * 64;                         // [KB][ls]
-    int32_t* ancs = reinterpret_cast<int32_t*>(sc + KB * ls);   // [KB][ls]
+    const int n_live = min(a.live_cnt[u], K * pos);
+    float* qs = reinterpret_cast<float*>(smem_raw);        // [BEAMS][64]
+    float* knew = qs + BEAMS * 64;                         // [BEAMS][64]
+    float* vnew = knew + BEAMS * 64;                       // [BEAMS][64]
+    int32_t* ancs = reinterpret_cast<int32_t*>(vnew + BEAMS * 64);   // [K][ls]
+    int32_t* live = ancs + K * ls;                         // [K * ls]  (position << 5 | slot)
+    // the merge buffers reuse the ancs/live area once the key loop is over
+    float (*wo)[NB][64][17] = reinterpret_cast<float (*)[NB][64][17]>(ancs);
+    float (*wm)[NB][16] = reinterpret_cast<float (*)[NB][16]>(reinterpret_cast<float*>(ancs) + 4 * NB * 64 * 17);
+    float (*wl)[NB][16] = wm + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = tid >> 4, c = tid & 15;
-
-    auto dot16 = [&](const f32x4& x, const f32x4& y) {
-        float d = (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
-        d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
-        return d;
-    };
+    const int g = lane >> 4, c = lane & 15;
 
     // ---- q, k, v of the new position: reduce the split-K slabs, add the bias, scale q (utils.py:628, Q3)
-    for (int i = tid; i < KB * 16; i += 256) {
-        const int kb = i >> 4;
+    for (int i = tid; i < BEAMS * 16; i += 256) {
+        const int kb = i >> 4, cc = i & 15;
         f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, v4 = q4;
         if (kb < K) {
-            const size_t rowoff = (size_t)(u * K + kb) * 3 * hidden + h * 64 + c * 4;
+            const size_t rowoff = (size_t)(u * K + kb) * 3 * hidden + h * 64 + cc * 4;
             for (int z = 0; z < a.nsplit; ++z) {
                 const float* p = a.qkv + z * a.split_stride + rowoff;
                 q4 += *reinterpret_cast<const f32x4*>(p);
                 k4 += *reinterpret_cast<const f32x4*>(p + hidden);
                 v4 += *reinterpret_cast<const f32x4*>(p + 2 * hidden);
             }
-            const float* bp = a.bias + h * 64 + c * 4;
+            const float* bp = a.bias + h * 64 + cc * 4;
             q4 += *reinterpret_cast<const f32x4*>(bp);
             k4 += *reinterpret_cast<const f32x4*>(bp + hidden);
             v4 += *reinterpret_cast<const f32x4*>(bp + 2 * hidden);
             q4 = q4 * 0.125f;
-            const size_t off = (((size_t)u * width + pos) * K + kb) * hidden + h * 64 + c * 4;
+            const size_t off = (((size_t)u * width + pos) * K + kb) * hidden + h * 64 + cc * 4;
             *reinterpret_cast<f32x4*>(a.kcache + off) = k4;
             *reinterpret_cast<f32x4*>(a.vcache + off) = v4;
         }
-        reinterpret_cast<f32x4*>(qs)[kb * 16 + c] = q4;
-        reinterpret_cast<f32x4*>(vnew)[kb * 16 + c] = v4;
-        const float d = dot16(q4, k4);
-        if (c == 0) sc[kb * ls + pos] = d;
+        reinterpret_cast<f32x4*>(qs)[kb * 16 + cc] = q4;
+        reinterpret_cast<f32x4*>(knew)[kb * 16 + cc] = k4;
+        reinterpret_cast<f32x4*>(vnew)[kb * 16 + cc] = v4;
     }
     {
         const int32_t* anc = ((pos & 1) ? a.anc1 : a.anc0) + (size_t)u * K * width;
@@ -201,70 +201,142 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
             const int kb = i / pos, j = i - kb * pos;
             ancs[kb * ls + j] = anc[(size_t)kb * width + j];
         }
+        const int32_t* lsrc = a.live + (size_t)u * K * width;
+        for (int i = tid; i < n_live; i += 256) live[i] = lsrc[i];
     }
     __syncthreads();
 
-    // ---- scores: group `grp` takes history positions j = grp, grp+16, ...
-    const size_t head_off = (size_t)h * 64 + c * 4;
-    for (int j = grp; j < pos; j += 16) {
-        const float* kbase = a.kcache + ((size_t)u * width + j) * K * hidden + head_off;
-        f32x4 kk[KB];
+    f32x4 qf[NB][4];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            kk[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kb < K) kk[kb] = *reinterpret_cast<const f32x4*>(kbase + (size_t)ancs[kb * ls + j] * hidden);
-        }
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const float d = dot16(reinterpret_cast<const f32x4*>(qs)[kb * 16 + c], kk[kb]);
-            if (c == 0) sc[kb * ls + j] = d;
-        }
+        for (int db = 0; db < 4; ++db) qf[nb][db] = reinterpret_cast<const f32x4*>(qs)[(nb * 16 + c) * 16 + db * 4 + g];
+    float m_run[NB], l_run[NB];
+    f32x4 o[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        m_run[nb] = -INFINITY; l_run[nb] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[nb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
 
-    // ---- softmax over positions 0..pos, one wave per beam
-    for (int kb = wave; kb < K; kb += 4) {
-        float* s = sc + kb * ls;
-        float m = -INFINITY;
-        for (int j = lane; j <= pos; j += 64) m = fmaxf(m, s[j]);
-        m = wave_max(m);
-        float sum = 0.f;
-        for (int j = lane; j <= pos; j += 64) { const float e = expf(s[j] - m); s[j] = e; sum += e; }
-        sum = wave_sum(sum);
-        for (int j = lane; j <= pos; j += 64) s[j] = s[j] / sum;
-    }
-    __syncthreads();
-
-    // ---- context: per-group partial sums over its positions, then groups -> wave -> workgroup
-    f32x4 o[KB];
+    // one block of 16 keys: kc4 = K rows (lane: key c, d = db*16 + 4g ..), vc4 = V rows (lane: key 4g+r, d = 4c ..),
+    // cj/cs = position (-1: the new position) and slot (-2: no such key) of key 4g+r
+    auto compute = [&](const f32x4 (&kc4)[4], const f32x4 (&vc4)[4], const int (&cj)[4], const int (&cs)[4]) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) o[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int j = grp; j < pos; j += 16) {
-        const float* vbase = a.vcache + ((size_t)u * width + j) * K * hidden + head_off;
-        f32x4 vv[KB];
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            vv[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kb < K) vv[kb] = *reinterpret_cast<const f32x4*>(vbase + (size_t)ancs[kb * ls + j] * hidden);
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc4[db][j], qf[nb][db][j], s, 0, 0, 0);
+            const int beam = nb * 16 + c, bl = min(beam, K - 1);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int want = (cj[r] < 0) ? beam : ancs[bl * ls + max(cj[r], 0)];
+                const bool ok = cs[r] >= 0 && beam < K && want == cs[r];
+                s[r] = ok ? s[r] : -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[nb], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;     // beam without a key so far: all weights 0
+            const float alpha = expf(m_run[nb] - m_use);
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] = expf(s[r] - m_use); lsum += s[r]; }
+            l_run[nb] = l_run[nb] * alpha + lsum;
+            m_run[nb] = m_new;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[nb][j] = o[nb][j] * alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc4[r][j], s[r], o[nb][j], 0, 0, 0);
         }
+    };
+
+    // ---- live history rows, 16 per block, blocks dealt round-robin to the 4 waves; loads are branch-free
+    // (clamped list index) and run one block ahead of the MFMAs
+    const int nblk = (n_live + 15) >> 4;
+    const size_t head_off = (size_t)h * 64;
+    f32x4 kf[4], vf[4];
+    int ej[4], es[4];
+    auto load_block = [&](int blk) {
+        const int key0 = blk * 16;
+        const int e = live[min(key0 + c, n_live - 1)];
+        const float* kr = a.kcache + (((size_t)u * width + (e >> 5)) * K + (e & 31)) * hidden + head_off + 4 * g;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) o[kb] += vv[kb] * sc[kb * ls + j];
+        for (int db = 0; db < 4; ++db) kf[db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = key0 + 4 * g + r;
+            const int er = live[min(idx, n_live - 1)];
+            vf[r] = *reinterpret_cast<const f32x4*>(a.vcache + (((size_t)u * width + (er >> 5)) * K + (er & 31)) * hidden + head_off + 4 * c);
+            ej[r] = er >> 5;
+            es[r] = idx < n_live ? (er & 31) : -2;
+        }
+    };
+    if (wave < nblk) load_block(wave);
+    for (int blk = wave; blk < nblk; blk += 4) {
+        f32x4 kc4[4], vc4[4];
+        int cj[4], cs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { kc4[i] = kf[i]; vc4[i] = vf[i]; cj[i] = ej[i]; cs[i] = es[i]; }
+        if (blk + 4 < nblk) load_block(blk + 4);
+        compute(kc4, vc4, cj, cs);
     }
+    // ---- the new position: key = beam, from LDS
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
+    for (int sb = 0; sb < NB; ++sb) {
+        if (wave == ((nblk + sb) & 3)) {
+            f32x4 kc4[4], vc4[4];
+            int cj[4], cs[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { o[kb][j] += __shfl_xor(o[kb][j], 16); o[kb][j] += __shfl_xor(o[kb][j], 32); }
-        if ((lane >> 4) == 0) reinterpret_cast<f32x4*>(red)[(wave * KB + kb) * 16 + c] = o[kb];
+            for (int db = 0; db < 4; ++db) kc4[db] = reinterpret_cast<const f32x4*>(knew)[(sb * 16 + c) * 16 + db * 4 + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kbm = sb * 16 + 4 * g + r;
+                vc4[r] = reinterpret_cast<const f32x4*>(vnew)[kbm * 16 + c];
+                cj[r] = -1;
+                cs[r] = kbm < K ? kbm : -2;
+            }
+            compute(kc4, vc4, cj, cs);
+        }
+    }
+    __syncthreads();                                       // every wave is done with ancs / live: reuse as merge buffers
+
+    // o[nb][j][r'] = O[beam nb*16+c][d = 16g + 4r' + j] of this wave's keys (unnormalised)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        float l = l_run[nb];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (g == 0) { wm[wave][nb][c] = m_run[nb]; wl[wave][nb][c] = l; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wo[wave][nb][16 * g + 4 * r + j][c] = o[nb][j][r];
     }
     __syncthreads();
-    for (int i = tid; i < KB * 16; i += 256) {
-        const int kb = i >> 4, cc = i & 15;
-        if (kb < K) {
-            const f32x4* rp = reinterpret_cast<const f32x4*>(red);
-            f32x4 v = (rp[(0 * KB + kb) * 16 + cc] + rp[(1 * KB + kb) * 16 + cc]) +
-                      (rp[(2 * KB + kb) * 16 + cc] + rp[(3 * KB + kb) * 16 + cc]);
-            v += reinterpret_cast<const f32x4*>(vnew)[kb * 16 + cc] * sc[kb * ls + pos];
-            *reinterpret_cast<f32x4*>(a.ctx + (size_t)(u * K + kb) * hidden + h * 64 + cc * 4) = v;
+    for (int i = tid; i < NB * 16 * 16; i += 256) {
+        const int beam = i >> 4, d4 = i & 15, nb = beam >> 4, bc = beam & 15;
+        if (beam < K) {
+            const float M = fmaxf(fmaxf(wm[0][nb][bc], wm[1][nb][bc]), fmaxf(wm[2][nb][bc], wm[3][nb][bc]));
+            float sc[4], L = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { sc[w] = expf(wm[w][nb][bc] - M); L += sc[w] * wl[w][nb][bc]; }
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc += sc[w] * wo[w][nb][4 * d4 + e][bc];
+                v[e] = acc / L;
+            }
+            *reinterpret_cast<f32x4*>(a.ctx + (size_t)(u * K + beam) * hidden + h * 64 + 4 * d4) = v;
         }
     }
 }
@@ -425,12 +497,27 @@ __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnA
     }
 }
 
-int cross_kb(int k) { return k <= 1 ? 1 : k <= 2 ? 2 : k <= 4 ? 4 : k <= 8 ? 8 : k <= 12 ? 12 : k <= 16 ? 16 : 32; }
+}  // namespace
 
-template <int KB>
+hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads, float* ctx, hipStream_t s)
+{
+    if (n <= 0 || t <= 0) return hipSuccess;
+    hipLaunchKernelGGL(encoder_attention_kernel, dim3((t + 127) / 128, heads, n), dim3(256), 0, s, qkv, pad, t, heads, ctx);
+    return hipGetLastError();
+}
+
+size_t self_attention_lds_bytes(int k, int lds_stride)
+{
+    const int nb = k <= 16 ? 1 : 2;
+    const size_t lists = (size_t)2 * k * lds_stride * sizeof(int32_t);
+    const size_t merge = (size_t)nb * (4 * 64 * 17 + 2 * 4 * 16) * sizeof(float);
+    return (size_t)3 * nb * 16 * 64 * sizeof(float) + (lists > merge ? lists : merge);
+}
+
+template <int NB>
 hipError_t launch_self(const SelfAttnArgs& a, size_t lds, hipStream_t s)
 {
-    auto kern = decoder_self_attention_kernel<KB>;
+    auto kern = decoder_self_attention_kernel<NB>;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -444,35 +531,13 @@ hipError_t launch_self(const SelfAttnArgs& a, size_t lds, hipStream_t s)
     return hipGetLastError();
 }
 
-}  // namespace
-
-hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads, float* ctx, hipStream_t s)
-{
-    if (n <= 0 || t <= 0) return hipSuccess;
-    hipLaunchKernelGGL(encoder_attention_kernel, dim3((t + 127) / 128, heads, n), dim3(256), 0, s, qkv, pad, t, heads, ctx);
-    return hipGetLastError();
-}
-
-size_t self_attention_lds_bytes(int k, int lds_stride)
-{
-    const int kb = cross_kb(k);
-    return ((size_t)kb * 64 * 6 + (size_t)2 * kb * lds_stride) * sizeof(float);
-}
-
 hipError_t launch_decoder_self_attention(const SelfAttnArgs& a, hipStream_t s)
 {
     if (a.b <= 0) return hipSuccess;
     const size_t lds = self_attention_lds_bytes(a.k, a.lds_stride);
-    if (lds > 150 * 1024 || a.k > ASR_MAX_BEAM || a.lds_stride > a.width || a.lds_stride < 2) return hipErrorInvalidValue;
-    switch (cross_kb(a.k)) {
-        case 1: return launch_self<1>(a, lds, s);
-        case 2: return launch_self<2>(a, lds, s);
-        case 4: return launch_self<4>(a, lds, s);
-        case 8: return launch_self<8>(a, lds, s);
-        case 12: return launch_self<12>(a, lds, s);
-        case 16: return launch_self<16>(a, lds, s);
-        default: return launch_self<32>(a, lds, s);
-    }
+    if (lds > 150 * 1024 || a.k > ASR_MAX_BEAM || a.lds_stride > a.width || a.lds_stride < 2 || !a.live || !a.live_cnt)
+        return hipErrorInvalidValue;
+    return a.k <= 16 ? launch_self<1>(a, lds, s) : launch_self<2>(a, lds, s);
 }
 
 hipError_t launch_decoder_cross_attention(const CrossAttnArgs& a, hipStream_t s)

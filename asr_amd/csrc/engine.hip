@@ -45,6 +45,8 @@ struct asr_handle {
     int H = 0, heads = 0, L = 0, V = 0, D = 0, F = 0, K = 0;
     bool glu = false;
     int ff_epi = EPI_RELU;
+    int nprod = 0;                      // 0: exact f32 MFMA GEMMs; 6 / 3 / 1: bf16 planes (gemm_split.hip)
+    float* emb_gemm = nullptr;          // logits operand when tied: = emb (f32 mode) or its bf16 planes
     hipStream_t stream = nullptr;
     mutable std::string err;
     std::map<std::string, HostTensor> staged;
@@ -154,32 +156,35 @@ struct ProfScope {
     }
 };
 
-const char* gemm_class_name(int M, int N, int epilogue)
+const char* gemm_class_name(int nprod, int M, int N, int epilogue)
 {
+    static std::map<std::string, std::string> interned;           // stable c_str() for ProfClass::name
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const bool big = tiles128 >= 512;
-    switch (epilogue) {
-        case EPI_GLU: return big ? "gemm_f32_nt<128,128,GLU>" : "gemm_f32_nt<64,64,GLU>";
-        case EPI_PARTIAL: return big ? "gemm_f32_nt<128,128,PARTIAL>" : "gemm_f32_nt<64,64,PARTIAL>";
-        case EPI_BIAS: return big ? "gemm_f32_nt<128,128,BIAS>" : "gemm_f32_nt<64,64,BIAS>";
-        default: return big ? "gemm_f32_nt<128,128,ACT>" : "gemm_f32_nt<64,64,ACT>";
-    }
+    std::string n = nprod == 0 ? "gemm_f32_nt" : nprod == 6 ? "gemm_bf16x6_nt" : nprod == 3 ? "gemm_bf16x3_nt" : "gemm_bf16_nt";
+    n += big ? "<128,128," : "<64,64,";
+    n += epilogue == EPI_GLU ? "GLU>" : epilogue == EPI_PARTIAL ? "PARTIAL>" : epilogue == EPI_BIAS ? "BIAS>" : "ACT>";
+    auto it = interned.find(n);
+    if (it == interned.end()) it = interned.emplace(n, n).first;
+    return it->second.c_str();
 }
 
 int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epilogue,
          int split_k)
 {
     GemmArgs a{};
-    a.A = A; a.W = W; a.bias = bias; a.C = C;
+    a.A = A; a.W = W; a.Wp = reinterpret_cast<const uint16_t*>(W); a.bias = bias; a.C = C;
     a.M = M; a.N = N; a.K = K;
     a.lda = K; a.ldw = K;
     a.ldc = (epilogue == EPI_GLU) ? N / 2 : N;
     a.split_k = split_k;
     a.epilogue = epilogue;
     const double nout = (epilogue == EPI_GLU) ? N / 2.0 : (double)N * split_k;
-    ProfScope ps(h, gemm_class_name(M, N, epilogue), 2.0 * M * N * (double)K,
-                 4.0 * ((double)M * K + (double)N * K + (double)M * nout));
-    HIP_TRY(h, launch_gemm_f32(a, 0, h->stream));
+    const double wbytes = h->nprod ? 2.0 * gemm_split_planes(h->nprod) : 4.0;
+    ProfScope ps(h, gemm_class_name(h->nprod, M, N, epilogue), 2.0 * M * N * (double)K,
+                 4.0 * ((double)M * K + (double)M * nout) + wbytes * (double)N * K);
+    if (h->nprod) HIP_TRY(h, launch_gemm_split(a, h->nprod, 0, h->stream));
+    else HIP_TRY(h, launch_gemm_f32(a, 0, h->stream));
     return ASR_OK;
 }
 
@@ -282,11 +287,37 @@ int upload(asr_handle* h, const std::string& name, float** dst)
     return ASR_OK;
 }
 
+// a GEMM operand: f32 [N][K] as is, or split into bf16 planes [planes][N][K] (gemm_split.hip)
+int upload_gemm_host(asr_handle* h, const float* w, size_t count, float** dst)
+{
+    if (h->nprod == 0) {
+        int rc = dev_alloc_t(h, dst, count);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpy(*dst, w, count * sizeof(float), hipMemcpyHostToDevice));
+        return ASR_OK;
+    }
+    const int npl = gemm_split_planes(h->nprod);
+    std::vector<uint16_t> planes((size_t)npl * count);
+    gemm_split_weights_host(w, count, npl, planes.data());
+    uint16_t* d = nullptr;
+    int rc = dev_alloc_t(h, &d, planes.size());
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(d, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    *dst = reinterpret_cast<float*>(d);
+    return ASR_OK;
+}
+
+int upload_gemm(asr_handle* h, const std::string& name, float** dst)
+{
+    const HostTensor& t = h->staged.at(name);
+    return upload_gemm_host(h, t.data.data(), t.data.size(), dst);
+}
+
 // ff_hidden first dense: GLU weights packed [2F][H] per 32 rows: 16 value rows | 16 gate rows
 int upload_ffn1(asr_handle* h, const std::string& p, float** w, float** b)
 {
     if (!h->glu) {
-        int rc = upload(h, p + "/ff_hidden/dense/kernel", w);
+        int rc = upload_gemm(h, p + "/ff_hidden/dense/kernel", w);
         if (rc) return rc;
         return upload(h, p + "/ff_hidden/dense/bias", b);
     }
@@ -303,11 +334,10 @@ int upload_ffn1(asr_handle* h, const std::string& p, float** w, float** b)
             bp[(size_t)g * 32 + r] = b1.data[(size_t)g * 16 + r];
             bp[(size_t)g * 32 + 16 + r] = b2.data[(size_t)g * 16 + r];
         }
-    int rc = dev_alloc_t(h, w, wp.size());
+    int rc = upload_gemm_host(h, wp.data(), wp.size(), w);
     if (rc) return rc;
     rc = dev_alloc_t(h, b, bp.size());
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpy(*w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(*b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
     return ASR_OK;
 }
@@ -350,9 +380,9 @@ int ensure_encoder_capacity(asr_handle* h, int n, int t)
 
 int decode_splits(const asr_handle* h, int R, int* s_qkv, int* s_proj, int* s_ffn2)
 {
-    *s_qkv = gemm_pick_split_k(R, 3 * h->H, h->H);
-    *s_proj = gemm_pick_split_k(R, h->H, h->H);
-    *s_ffn2 = gemm_pick_split_k(R, h->H, h->F);
+    *s_qkv = gemm_pick_split_k(R, 3 * h->H, h->H, h->nprod);
+    *s_proj = gemm_pick_split_k(R, h->H, h->H, h->nprod);
+    *s_ffn2 = gemm_pick_split_k(R, h->H, h->F, h->nprod);
     return 0;
 }
 
@@ -369,7 +399,8 @@ int ensure_decoder_capacity(asr_handle* h, int n)
     h->kcache.assign(h->L, nullptr);
     h->vcache.assign(h->L, nullptr);
     void* bs[] = {h->beam.scores[0], h->beam.scores[1], h->beam.finished[0], h->beam.finished[1], h->beam.preds[0],
-                  h->beam.preds[1], h->beam.anc[0], h->beam.anc[1], h->beam.pos, h->beam.tokens, h->beam.parents};
+                  h->beam.preds[1], h->beam.anc[0], h->beam.anc[1], h->beam.pos, h->beam.tokens, h->beam.parents,
+                  h->beam.live, h->beam.live_cnt};
     for (auto p : bs) dev_free(h, p);
     h->beam = BeamState{};
 
@@ -396,6 +427,8 @@ int ensure_decoder_capacity(asr_handle* h, int n)
     rc |= dev_alloc_t(h, &h->beam.pos, 4);
     rc |= dev_alloc_t(h, &h->beam.tokens, R);
     rc |= dev_alloc_t(h, &h->beam.parents, R);
+    rc |= dev_alloc_t(h, &h->beam.live, R * width);
+    rc |= dev_alloc_t(h, &h->beam.live_cnt, (size_t)n);
     if (rc) return ASR_ERR_HIP;
     h->beam.done = h->beam.pos + 1;
     h->beam.unfinished = h->beam.pos + 2;
@@ -485,7 +518,7 @@ int run_decode_step(asr_handle* h, int n, int t)
             SelfAttnArgs a{};
             a.qkv = h->part; a.nsplit = s_qkv; a.split_stride = 3 * RH; a.bias = b.bqkv;
             a.kcache = h->kcache[l]; a.vcache = h->vcache[l];
-            a.anc0 = st.anc[0]; a.anc1 = st.anc[1]; a.pos = st.pos; a.done = st.done;
+            a.anc0 = st.anc[0]; a.anc1 = st.anc[1]; a.live = st.live; a.live_cnt = st.live_cnt; a.pos = st.pos; a.done = st.done;
             a.ctx = h->dctx; a.b = n; a.k = K; a.heads = h->heads; a.width = st.width;
             a.lds_stride = std::min(st.width, st.limit + 2);
             ProfScope ps(h, "decoder_self_attention", 0, 0);
@@ -525,7 +558,7 @@ int run_decode_step(asr_handle* h, int n, int t)
                                                   h->y0, st.done, s));
         }
     }
-    const float* wout = h->cfg.tie_embedding_and_softmax ? h->emb : h->softmax_w;
+    const float* wout = h->cfg.tie_embedding_and_softmax ? h->emb_gemm : h->softmax_w;
     int rc = gemm(h, h->y0, wout, nullptr, h->logits, R, h->V, H, EPI_BIAS, 1);                     // model.py:341
     if (rc) return rc;
     {
@@ -646,6 +679,19 @@ struct TmpBufs {
         if (src) e = hipMemcpyAsync(*d, src, count * sizeof(T), hipMemcpyHostToDevice, s);
         return e;
     }
+    // a GEMM weight operand in the handle's precision mode (f32, or bf16 planes)
+    int up_gemm(asr_handle* h, float** d, const float* w, size_t count, hipStream_t s)
+    {
+        if (h->nprod == 0) { HIP_TRY(h, up(d, w, count, s)); return ASR_OK; }
+        const int npl = gemm_split_planes(h->nprod);
+        std::vector<uint16_t> planes((size_t)npl * count);
+        gemm_split_weights_host(w, count, npl, planes.data());
+        uint16_t* dp = nullptr;
+        HIP_TRY(h, up(&dp, planes.data(), planes.size(), s));
+        HIP_TRY(h, hipStreamSynchronize(s));                   // `planes` is a local
+        *d = reinterpret_cast<float*>(dp);
+        return ASR_OK;
+    }
 };
 
 }  // namespace
@@ -677,6 +723,11 @@ int asr_create(const asr_config* cfg, asr_handle** out)
         return bad("dst_vocab_size must be in [max(4, beam_size), 38400]");
     if (cfg->max_target_length < 1 || cfg->max_target_length > 4000) return bad("max_target_length must be in 1..4000");
     if (cfg->ff_activation < ASR_FF_RELU || cfg->ff_activation > ASR_FF_SWISH) return bad("unknown ff_activation");
+    if (cfg->precision < ASR_PRECISION_F32 || cfg->precision > ASR_PRECISION_BF16) return bad("unknown precision");
+    if (cfg->precision != ASR_PRECISION_F32 && (cfg->input_dim & 31))
+        return bad("the bf16-plane GEMM modes need input_dim % 32 == 0 (use precision = ASR_PRECISION_F32)");
+    for (int i = 0; i < 3; ++i)
+        if (cfg->reserved[i]) return bad("reserved fields must be zero");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device visible (libasr_amd needs an MI355X)"; return ASR_ERR_HIP; }
     if (cfg->device < 0 || cfg->device >= ndev) return bad("device ordinal out of range");
@@ -686,6 +737,8 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     h->H = cfg->hidden_units; h->heads = cfg->num_heads; h->L = cfg->num_blocks; h->V = cfg->dst_vocab_size;
     h->D = cfg->input_dim; h->F = 4 * cfg->hidden_units; h->K = cfg->beam_size;
     h->glu = cfg->ff_activation == ASR_FF_GLU;
+    h->nprod = cfg->precision == ASR_PRECISION_F32_BF16X6 ? 6 : cfg->precision == ASR_PRECISION_BF16X3 ? 3
+             : cfg->precision == ASR_PRECISION_BF16 ? 1 : 0;
     switch (cfg->ff_activation) {
         case ASR_FF_SIGMOID: h->ff_epi = EPI_SIGMOID; break;
         case ASR_FF_TANH: h->ff_epi = EPI_TANH; break;
@@ -767,25 +820,31 @@ int asr_finalize_weights(asr_handle* h)
     for (const VarSpec& v : required_vars(h))
         if (!h->staged.count(v.name)) { if (nmiss++ < 12) missing += "\n  " + v.name; }
     if (nmiss) return fail(h, ASR_ERR_WEIGHTS, std::to_string(nmiss) + " variable(s) missing:" + missing + (nmiss > 12 ? "\n  ..." : ""));
-    if ((rc = upload(h, "encoder/src_change/kernel", &h->w_src))) return rc;
+    if ((rc = upload_gemm(h, "encoder/src_change/kernel", &h->w_src))) return rc;
     if ((rc = upload(h, "encoder/src_change/bias", &h->b_src))) return rc;
     if ((rc = upload(h, "encoder/LayerNorm/gamma", &h->in_gamma))) return rc;
     if ((rc = upload(h, "encoder/LayerNorm/beta", &h->in_beta))) return rc;
-    if ((rc = upload(h, "decoder/dst_embedding/kernel", &h->emb))) return rc;
-    if (!h->cfg.tie_embedding_and_softmax && (rc = upload(h, "decoder/softmax/kernel", &h->softmax_w))) return rc;
+    if ((rc = upload(h, "decoder/dst_embedding/kernel", &h->emb))) return rc;          // f32: the embedding lookup
+    if (!h->cfg.tie_embedding_and_softmax) {
+        if ((rc = upload_gemm(h, "decoder/softmax/kernel", &h->softmax_w))) return rc;
+    } else if (h->nprod) {
+        if ((rc = upload_gemm(h, "decoder/dst_embedding/kernel", &h->emb_gemm))) return rc;
+    } else {
+        h->emb_gemm = h->emb;
+    }
     h->enc.resize(h->L);
     h->dec.resize(h->L);
     for (int i = 0; i < h->L; ++i) {
         const std::string p = "encoder/block_" + std::to_string(i);
         EncBlock& b = h->enc[i];
-        if ((rc = upload(h, p + "/encoder_self_attention/qkv_transform/kernel", &b.wqkv))) return rc;
+        if ((rc = upload_gemm(h, p + "/encoder_self_attention/qkv_transform/kernel", &b.wqkv))) return rc;
         if ((rc = upload(h, p + "/encoder_self_attention/qkv_transform/bias", &b.bqkv))) return rc;
-        if ((rc = upload(h, p + "/encoder_self_attention/output_transform/kernel", &b.wo))) return rc;
+        if ((rc = upload_gemm(h, p + "/encoder_self_attention/output_transform/kernel", &b.wo))) return rc;
         if ((rc = upload(h, p + "/encoder_self_attention/output_transform/bias", &b.bo))) return rc;
         if ((rc = upload(h, p + "/layer_norm/layer_norm_scale", &b.ln0s))) return rc;
         if ((rc = upload(h, p + "/layer_norm/layer_norm_bias", &b.ln0b))) return rc;
         if ((rc = upload_ffn1(h, p, &b.w1, &b.b1))) return rc;
-        if ((rc = upload(h, p + "/ff_hidden/dense_1/kernel", &b.w2))) return rc;
+        if ((rc = upload_gemm(h, p + "/ff_hidden/dense_1/kernel", &b.w2))) return rc;
         if ((rc = upload(h, p + "/ff_hidden/dense_1/bias", &b.b2))) return rc;
         if ((rc = upload(h, p + "/layer_norm_1/layer_norm_scale", &b.ln1s))) return rc;
         if ((rc = upload(h, p + "/layer_norm_1/layer_norm_bias", &b.ln1b))) return rc;
@@ -793,22 +852,22 @@ int asr_finalize_weights(asr_handle* h)
     for (int i = 0; i < h->L; ++i) {
         const std::string p = "decoder/block_" + std::to_string(i);
         DecBlock& b = h->dec[i];
-        if ((rc = upload(h, p + "/decoder_self_attention/qkv_transform/kernel", &b.wqkv))) return rc;
+        if ((rc = upload_gemm(h, p + "/decoder_self_attention/qkv_transform/kernel", &b.wqkv))) return rc;
         if ((rc = upload(h, p + "/decoder_self_attention/qkv_transform/bias", &b.bqkv))) return rc;
-        if ((rc = upload(h, p + "/decoder_self_attention/output_transform/kernel", &b.wo))) return rc;
+        if ((rc = upload_gemm(h, p + "/decoder_self_attention/output_transform/kernel", &b.wo))) return rc;
         if ((rc = upload(h, p + "/decoder_self_attention/output_transform/bias", &b.bo))) return rc;
         if ((rc = upload(h, p + "/layer_norm/layer_norm_scale", &b.ln0s))) return rc;
         if ((rc = upload(h, p + "/layer_norm/layer_norm_bias", &b.ln0b))) return rc;
-        if ((rc = upload(h, p + "/decoder_vanilla_attention/q_transform/kernel", &b.wq))) return rc;
+        if ((rc = upload_gemm(h, p + "/decoder_vanilla_attention/q_transform/kernel", &b.wq))) return rc;
         if ((rc = upload(h, p + "/decoder_vanilla_attention/q_transform/bias", &b.bq))) return rc;
-        if ((rc = upload(h, p + "/decoder_vanilla_attention/kv_transform/kernel", &b.wkv))) return rc;
+        if ((rc = upload_gemm(h, p + "/decoder_vanilla_attention/kv_transform/kernel", &b.wkv))) return rc;
         if ((rc = upload(h, p + "/decoder_vanilla_attention/kv_transform/bias", &b.bkv))) return rc;
-        if ((rc = upload(h, p + "/decoder_vanilla_attention/output_transform/kernel", &b.wco))) return rc;
+        if ((rc = upload_gemm(h, p + "/decoder_vanilla_attention/output_transform/kernel", &b.wco))) return rc;
         if ((rc = upload(h, p + "/decoder_vanilla_attention/output_transform/bias", &b.bco))) return rc;
         if ((rc = upload(h, p + "/layer_norm_1/layer_norm_scale", &b.ln1s))) return rc;
         if ((rc = upload(h, p + "/layer_norm_1/layer_norm_bias", &b.ln1b))) return rc;
         if ((rc = upload_ffn1(h, p, &b.w1, &b.b1))) return rc;
-        if ((rc = upload(h, p + "/ff_hidden/dense_1/kernel", &b.w2))) return rc;
+        if ((rc = upload_gemm(h, p + "/ff_hidden/dense_1/kernel", &b.w2))) return rc;
         if ((rc = upload(h, p + "/ff_hidden/dense_1/bias", &b.b2))) return rc;
         if ((rc = upload(h, p + "/layer_norm_2/layer_norm_scale", &b.ln2s))) return rc;
         if ((rc = upload(h, p + "/layer_norm_2/layer_norm_bias", &b.ln2b))) return rc;
@@ -907,13 +966,14 @@ int asr_op_dense(asr_handle* h, const float* x, const float* w, const float* bia
 {
     if (!h || !x || !w || !y || m < 1 || n < 1 || k < 4 || (k & 3) || split_k < 1 || split_k > ASR_MAX_SPLITK)
         return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    if (h->nprod && (k & 31)) return fail(h, ASR_ERR_ARG, "the bf16-plane GEMM modes need k % 32 == 0");
     int rc = set_device(h);
     if (rc) return rc;
     TmpBufs tb;
     float *dx, *dw, *db = nullptr, *dy, *dpart = nullptr;
     hipStream_t s = h->stream;
     HIP_TRY(h, tb.up(&dx, x, (size_t)m * k, s));
-    HIP_TRY(h, tb.up(&dw, w, (size_t)n * k, s));
+    if ((rc = tb.up_gemm(h, &dw, w, (size_t)n * k, s))) return rc;
     if (bias) HIP_TRY(h, tb.up(&db, bias, (size_t)n, s));
     HIP_TRY(h, tb.up<float>(&dy, nullptr, (size_t)m * n, s));
     if (split_k == 1) {
@@ -943,6 +1003,7 @@ int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float
 {
     if (!h || !x || !w1 || !w2 || !y || m < 1 || n < 16 || (n & 15) || k < 4 || (k & 3))
         return h ? fail(h, ASR_ERR_ARG, "bad argument (n must be a multiple of 16)") : ASR_ERR_ARG;
+    if (h->nprod && (k & 31)) return fail(h, ASR_ERR_ARG, "the bf16-plane GEMM modes need k % 32 == 0");
     int rc = set_device(h);
     if (rc) return rc;
     std::vector<float> wp((size_t)2 * n * k), bp((size_t)2 * n, 0.f);
@@ -957,7 +1018,7 @@ int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float
     float *dx, *dw, *db, *dy;
     hipStream_t s = h->stream;
     HIP_TRY(h, tb.up(&dx, x, (size_t)m * k, s));
-    HIP_TRY(h, tb.up(&dw, wp.data(), wp.size(), s));
+    if ((rc = tb.up_gemm(h, &dw, wp.data(), wp.size(), s))) return rc;
     HIP_TRY(h, tb.up(&db, bp.data(), bp.size(), s));
     HIP_TRY(h, tb.up<float>(&dy, nullptr, (size_t)m * n, s));
     if ((rc = gemm(h, dx, dw, db, dy, m, 2 * n, k, EPI_GLU, 1))) return rc;

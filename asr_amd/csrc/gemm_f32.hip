@@ -10,6 +10,7 @@
 // 2q+1: the MFMA k index is only a summation label, so any A/B-consistent assignment is valid).
 // LDS image: [rows][8 chunks of 16 B] with the chunk XOR-swizzled by (row & 7).
 #include "asr_common.h"
+#include "gemm_epilogue.h"
 #include <math.h>
 #include <type_traits>
 
@@ -23,7 +24,6 @@ bool g_force_reg_stage = false;   // development / test switch (asr_gemm_force_r
 
 typedef __attribute__((address_space(3))) void* LdsPtr;
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // DMA = true: tiles are staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no
 // ds_write); needs K % 32 == 0.  DMA = false: register-staged path for any K % 4 == 0.
@@ -229,52 +229,7 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, 
         }
     }
 
-    // ---- epilogue: acc reg r of lane l is C[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31] of its 32x32 fragment
-    if constexpr (EPI == EPI_GLU) {
-        // W rows are packed in groups of 32: 16 value rows | 16 gate rows, so every 32-column fragment
-        // holds its own pairs: lanes 0-15 the value, lanes 16-31 the gate of the same 16 output columns.
-        const int nout = p.N >> 1;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int n = 0; n < NI; ++n) {
-                const int pcol = n0 + wn0 + n * 32 + l31;            // packed column
-                const int col = ((n0 + wn0 + n * 32) >> 1) + (l31 & 15);
-                const float bb = (p.bias && pcol < p.N) ? p.bias[pcol] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float mine = acc[i][n][r] + bb;
-                    const float gate = __shfl_down(mine, 16);
-                    const int gm = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    if (l31 < 16 && col < nout && gm < p.M) p.C[(size_t)gm * p.ldc + col] = mine * sigmoidf_(gate);
-                }
-            }
-    } else {
-        float* C = p.C;
-        if constexpr (EPI == EPI_PARTIAL) C += (size_t)z * p.M * p.ldc;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int n = 0; n < NI; ++n) {
-                const int col = n0 + wn0 + n * 32 + l31;
-                if (col < p.N) {
-                    float b = 0.f;
-                    if constexpr (EPI != EPI_PARTIAL) b = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int gm = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                        if (gm < p.M) {
-                            float v = acc[i][n][r] + b;
-                            if constexpr (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-                            if constexpr (EPI == EPI_SIGMOID) v = sigmoidf_(v);
-                            if constexpr (EPI == EPI_TANH) v = tanhf(v);
-                            if constexpr (EPI == EPI_SWISH) v = v * sigmoidf_(v);
-                            C[(size_t)gm * p.ldc + col] = v;
-                        }
-                    }
-                }
-            }
-    }
+    gemm_store_tile<EPI, MI, NI>(p, acc, m0, n0, wm0, wn0, z, lane);
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
@@ -323,12 +278,14 @@ hipError_t launch_epi(const GemmArgs& a, int tile, hipStream_t s)
 
 void gemm_force_reg_stage(bool on) { g_force_reg_stage = on; }
 
-int gemm_pick_split_k(int M, int N, int K)
+int gemm_pick_split_k(int M, int N, int K, int nprod)
 {
     // Decode-time projections (M = batch*beam rows) run 64x64 tiles, 4 waves each.  The f32 MFMA pipe is
     // the bound, so what matters is how evenly the waves fill the 1024 SIMDs: w waves per SIMD cost
     // ceil(w) turns of (K / split) / 32 k-tiles (0.45 us each); every extra slab costs one more write +
     // read of M x N floats.  Constants fitted to tools/gemm_bench.hip on MI355X.
+    // bf16-plane modes: a k-tile costs nprod 32-cycle MFMAs per 16-deep step instead of eight 64-cycle ones
+    const double ktile_us = nprod == 0 ? 0.45 : 0.45 * (nprod * 32.0) / 512.0 + 0.05;
     const double tiles = (double)((M + 63) / 64) * ((N + 63) / 64);
     const double w1 = tiles * 4.0 / 1024.0;
     int best = 1;
@@ -336,7 +293,7 @@ int gemm_pick_split_k(int M, int N, int K)
     for (int split = 1; split <= ASR_MAX_SPLITK; split *= 2) {
         if (split > 1 && K / split < 128) break;
         const double ktiles = ceil((double)K / split / 32.0);
-        const double t = ceil(w1 * split - 1e-9) * ktiles * 0.45 + split * (double)M * N * 4.0 / 4.0e6;
+        const double t = ceil(w1 * split - 1e-9) * ktiles * ktile_us + split * (double)M * N * 4.0 / 4.0e6;
         if (t < best_t - 1e-9) { best_t = t; best = split; }
     }
     return best;

@@ -421,6 +421,7 @@ __global__ void beam_init_kernel(BeamState st, int rows, int k)
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r == 0) { *st.pos = 0; *st.done = 0; *st.unfinished = 0; }
     if (r >= rows) return;
+    if (r % k == 0) st.live_cnt[r / k] = 0;                  // no history before the first step
     st.scores[0][r] = (r % k == 0) ? 0.0f : -1e10f;          // model.py:264-265
     st.finished[0][r] = 0;                                   // :266
     st.preds[0][(size_t)r * st.width] = 2;                   // <S>  (:263)
@@ -453,6 +454,40 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
         int any = 0;
         for (int i = 0; i < k; ++i) any |= (L.ntok[i] != 3);
         if (any) atomicAdd(st.unfinished, 1);
+    }
+    // Live rows of the K/V cache for the next step's self-attention: (position j, slot) pairs that at least one
+    // of the new beams descends from, j = 0..pos, ordered by j then slot.  Each thread owns a contiguous run of
+    // positions; a workgroup-wide exclusive scan of the per-thread counts gives the write offsets.
+    {
+        __shared__ int scan[256];
+        const int npos = pos + 1, chunk = (npos + 255) / 256;
+        const int j0 = min(tid * chunk, npos), j1 = min(j0 + chunk, npos);
+        auto slots_of = [&](int j) {
+            unsigned m = 0;
+            for (int b = 0; b < k; ++b) {
+                const int par = L.npar[b];
+                const int sl = (j < pos) ? st.anc[cur][(size_t)(u * k + par) * w + j] : par;
+                m |= 1u << sl;
+            }
+            return m;
+        };
+        int cnt = 0;
+        for (int j = j0; j < j1; ++j) cnt += __popc(slots_of(j));
+        scan[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {            // Hillis-Steele inclusive scan
+            const int v = (tid >= off) ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        int o = scan[tid] - cnt;
+        int32_t* dst = st.live + (size_t)u * k * w;
+        for (int j = j0; j < j1; ++j) {
+            unsigned m = slots_of(j);
+            while (m) { const int sl = __ffs(m) - 1; m &= m - 1; dst[o++] = (j << 5) | sl; }
+        }
+        if (tid == 255) st.live_cnt[u] = scan[255];
     }
 }
 
@@ -574,8 +609,17 @@ hipError_t launch_log_softmax_topk(const float* logits, int rows, int vocab, int
     return hipGetLastError();
 }
 
+static bool beam_state_ok(const BeamState& st, int b, int k)
+{
+    if (b < 1 || k < 1 || k > ASR_MAX_BEAM || st.width < 2) return false;
+    for (int i = 0; i < 2; ++i)
+        if (!st.scores[i] || !st.finished[i] || !st.preds[i] || !st.anc[i]) return false;
+    return st.live && st.live_cnt && st.pos && st.done && st.unfinished && st.tokens && st.parents;
+}
+
 hipError_t launch_beam_init(const BeamState& st, int b, int k, hipStream_t s)
 {
+    if (!beam_state_ok(st, b, k)) return hipErrorInvalidValue;      // a null table would fault the card
     const int rows = b * k;
     hipLaunchKernelGGL(beam_init_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, st, rows, k);
     return hipGetLastError();
@@ -584,6 +628,7 @@ hipError_t launch_beam_init(const BeamState& st, int b, int k, hipStream_t s)
 hipError_t launch_beam_step(const BeamState& st, const float* cand_scores, const int32_t* cand_tokens, int b, int k,
                             hipStream_t s)
 {
+    if (!beam_state_ok(st, b, k) || !cand_scores || !cand_tokens) return hipErrorInvalidValue;
     hipLaunchKernelGGL(beam_step_kernel, dim3(b), dim3(256), 0, s, st, cand_scores, cand_tokens, k);
     hipLaunchKernelGGL(beam_loop_ctl_kernel, dim3(1), dim3(1), 0, s, st);
     return hipGetLastError();

@@ -41,6 +41,12 @@ class Engine(object):
         c.max_target_length = int(t.max_target_length)
         c.lp_alpha = float(t.lp_alpha)
         c.device = int(device)
+        # build extension (not a reference key): arithmetic of the dense layers, see include/asr_amd.h asr_precision
+        prec = (t.precision if t.precision is not None else os.environ.get('ASR_AMD_PRECISION')) or 'f32'
+        if prec not in _lib.PRECISIONS:
+            raise ValueError('unknown test.precision %r (one of %s)' % (prec, sorted(_lib.PRECISIONS)))
+        c.precision = _lib.PRECISIONS[prec]
+        self.precision = prec
         self.cfg = c
         self.device = int(device)
         self._h = C.c_void_p()

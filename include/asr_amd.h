@@ -35,6 +35,15 @@ enum asr_status {
 
 enum asr_ff_activation { ASR_FF_RELU = 0, ASR_FF_GLU = 1, ASR_FF_SIGMOID = 2, ASR_FF_TANH = 3, ASR_FF_SWISH = 4 };
 
+/* Arithmetic of the dense layers (utils.dense).  The reference computes in float32 (model.py:35); every mode
+ * accumulates in float32 and keeps activations, attention, layer norms and the beam search in float32.
+ *   F32         exact-f32 matrix instructions (v_mfma_f32_32x32x2_f32): products and sums in f32.
+ *   F32_BF16X6  float32 operands split exactly into three bf16 terms each, six bf16 matrix products per k-step
+ *               (terms below 2^-24 of the product dropped): f32-chain accuracy at 2.7x the matrix rate.
+ *   BF16X3      two terms each, three products (~2^-16 relative product error).
+ *   BF16        operands rounded to bf16 (north_star's "bf16 MFMA" mode; tolerance stated in the tests). */
+enum asr_precision { ASR_PRECISION_F32 = 0, ASR_PRECISION_F32_BF16X6 = 1, ASR_PRECISION_BF16X3 = 2, ASR_PRECISION_BF16 = 3 };
+
 /* Model + search configuration: the YAML keys read by the inference graph
  * (model.py:19-45,434-442; config_template_*.yaml). */
 typedef struct asr_config {
@@ -50,7 +59,8 @@ typedef struct asr_config {
     int32_t max_target_length;           /* test.max_target_length                        */
     float   lp_alpha;                    /* test.lp_alpha                                 */
     int32_t device;                      /* HIP device ordinal this handle lives on       */
-    int32_t reserved[4];                 /* must be zero                                  */
+    int32_t precision;                   /* enum asr_precision (build extension; YAML key test.precision, default f32) */
+    int32_t reserved[3];                 /* must be zero                                  */
 } asr_config;
 
 /* Number of HIP devices visible to this process (0 when there is none or on error).  Replaces the

@@ -4,9 +4,10 @@ import numpy as np
 from oracle import asr_oracle as O
 
 
-def product_config(ocfg, num_gpus=1):
+def product_config(ocfg, num_gpus=1, precision=None):
     """oracle Config -> the AttrDict shape the product reads from the YAML files."""
     from asr_amd.utils import AttrDict
+    test_extra = {'precision': precision} if precision else {}       # build extension key (include/asr_amd.h asr_precision)
     return AttrDict({
         'model': 'Transformer',
         'dst_vocab_size': ocfg.dst_vocab_size,
@@ -18,7 +19,7 @@ def product_config(ocfg, num_gpus=1):
         'ff_activation': ocfg.ff_activation,
         'train': {'input_dim': ocfg.input_dim},
         'test': {'batch_size': 8, 'max_target_length': ocfg.max_target_length, 'lp_alpha': ocfg.lp_alpha,
-                 'beam_size': ocfg.beam_size, 'num_gpus': num_gpus},
+                 'beam_size': ocfg.beam_size, 'num_gpus': num_gpus, **test_extra},
     })
 
 

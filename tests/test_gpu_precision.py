@@ -1,0 +1,140 @@
+"""Arithmetic modes of the dense layers (include/asr_amd.h `asr_precision`; YAML extension key
+`test.precision`).  The reference computes in float32 (model.py:35):
+
+* `f32` (default)   exact-f32 matrix instructions.
+* `f32_bf16x6`      float32 operands split exactly into three bf16 terms, six bf16 matrix products per k-step,
+                    float32 accumulate.  Held to the SAME bars as `f32`: dense error vs float64 no larger than
+                    the exact-f32 kernel's bar, hypotheses identical to the oracle.
+* `bf16x3`          three products; tolerance 1e-4 on a dense layer.
+* `bf16`            north_star's "bf16 MFMA" mode, tolerance stated separately: 2e-2 relative on a dense
+                    layer, 5e-2 on first-step logits; hypotheses are NOT required to match (they need not on
+                    random-init models, whose posteriors are nearly flat).
+"""
+import numpy as np
+import pytest
+
+from oracle import asr_oracle as O
+from tests.helpers import product_config, rel_err, tiny_config, tiny_inputs
+
+pytestmark = pytest.mark.gpu
+
+DENSE_TOL = {'f32': 2e-6, 'f32_bf16x6': 2e-6, 'bf16x3': 1e-4, 'bf16': 2e-2}
+
+
+def _engine(ocfg, precision, W=None):
+    from asr_amd.model import Engine
+    e = Engine(product_config(ocfg, precision=precision), 0)
+    if W is not None:
+        e.load_weights(W)
+    return e
+
+
+@pytest.fixture(scope='module', params=list(DENSE_TOL))
+def mode_eng(request):
+    e = _engine(tiny_config(), request.param)
+    yield request.param, e
+    e.close()
+
+
+def _dense(eng, x, w, b, split_k=1):
+    from asr_amd import _lib as L
+    m, k = x.shape
+    n = w.shape[0]
+    y = np.empty((m, n), np.float32)
+    L.check(eng._h, L.lib.asr_op_dense(eng._h, L.fptr(x), L.fptr(w), L.fptr(b), m, n, k, split_k, L.fptr(y)))
+    return y
+
+
+@pytest.mark.parametrize('m,n,k,split', [(37, 50, 128, 1), (640, 3072, 1024, 1), (640, 1024, 1024, 4),
+                                         (640, 1024, 4096, 8), (30, 3900, 1024, 1), (2000, 1024, 320, 1),
+                                         (129, 257, 64, 2), (2672, 1024, 1024, 1)])
+def test_dense_modes(mode_eng, m, n, k, split):
+    mode, eng = mode_eng
+    rng = np.random.default_rng(m * 7 + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    want = x.astype(np.float64) @ w.astype(np.float64).T + b
+    got = _dense(eng, x, w, b, split)
+    assert rel_err(got, want) < DENSE_TOL[mode]
+    assert rel_err(_dense(eng, x, w, None, split), want - b) < DENSE_TOL[mode]
+
+
+def test_bf16x6_error_not_worse_than_exact_f32():
+    """The split-product path must be as accurate as the exact-f32 MFMA path (rms error vs float64)."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((640, 1024)).astype(np.float32)
+    w = rng.uniform(-0.05, 0.05, (1024, 1024)).astype(np.float32)
+    want = x.astype(np.float64) @ w.astype(np.float64).T
+    rms = {}
+    for mode in ('f32', 'f32_bf16x6'):
+        e = _engine(tiny_config(), mode)
+        try:
+            rms[mode] = float(np.sqrt(np.mean((_dense(e, x, w, None).astype(np.float64) - want) ** 2)))
+        finally:
+            e.close()
+    assert rms['f32_bf16x6'] <= 1.5 * rms['f32'], rms
+
+
+def test_dense_glu_modes(mode_eng):
+    from asr_amd import _lib as L
+    mode, eng = mode_eng
+    m, n, k = 640, 1024, 256
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w1 = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    w2 = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b1 = rng.standard_normal(n).astype(np.float32)
+    b2 = rng.standard_normal(n).astype(np.float32)
+    y = np.empty((m, n), np.float32)
+    L.check(eng._h, L.lib.asr_op_dense_glu(eng._h, L.fptr(x), L.fptr(w1), L.fptr(b1), L.fptr(w2), L.fptr(b2), m, n, k, L.fptr(y)))
+    x64 = x.astype(np.float64)
+    want = (x64 @ w1.astype(np.float64).T + b1) / (1.0 + np.exp(-(x64 @ w2.astype(np.float64).T + b2)))
+    assert rel_err(y, want) < 10 * DENSE_TOL[mode]
+
+
+CASES = [
+    dict(name='tiny_beam3', cfg=dict(), lens=(60, 90, 75), seed=1),
+    dict(name='tiny_beam10_tied', cfg=dict(beam_size=10, tie_embedding_and_softmax=True, max_target_length=25), lens=(100, 40), seed=3),
+    dict(name='mid_beam4_relu', cfg=dict(hidden_units=256, num_heads=4, num_blocks=3, dst_vocab_size=300, beam_size=4,
+                                         ff_activation='relu', max_target_length=30), lens=(150, 200, 120, 90, 201), seed=4),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
+def test_bf16x6_hypotheses_and_logits_match_oracle(case):
+    ocfg = tiny_config(**case['cfg'])
+    W = O.random_weights(ocfg, seed=case['seed'], bias_scale=0.1)
+    X = tiny_inputs(case['lens'], seed=case['seed'] + 10)
+    eng = _engine(ocfg, 'f32_bf16x6', W)
+    try:
+        Wc = O.cast_weights(W, np.float64)
+        enc64, _ = O.encoder(X.astype(np.float64), Wc, ocfg)
+        enc_gpu, _ = eng.encode(X)
+        assert rel_err(enc_gpu, enc64) < 1e-4
+        trace = {}
+        want = O.beam_search(enc64, Wc, ocfg, algo='kv', trace=trace)
+        Y, tr = eng.decode_trace(X, 2)
+        assert Y.shape == want.shape and np.array_equal(Y, want)
+        assert rel_err(tr['logits'][0], trace['logits'][0]) < 1e-3      # north_star bar; observed ~1e-5
+    finally:
+        eng.close()
+
+
+def test_bf16_mode_logits_within_stated_tolerance():
+    ocfg = tiny_config()
+    W = O.random_weights(ocfg, seed=1, bias_scale=0.1)
+    X = tiny_inputs((60, 90, 75), seed=11)
+    eng = _engine(ocfg, 'bf16', W)
+    try:
+        Wc = O.cast_weights(W, np.float64)
+        enc64, _ = O.encoder(X.astype(np.float64), Wc, ocfg)
+        enc_gpu, _ = eng.encode(X)
+        assert rel_err(enc_gpu, enc64) < 5e-2
+        trace = {}
+        O.beam_search(enc64, Wc, ocfg, algo='kv', trace=trace)
+        Y, tr = eng.decode_trace(X, 1)
+        assert rel_err(tr['logits'][0], trace['logits'][0]) < 5e-2
+        assert Y.dtype == np.int32 and Y.shape[0] == X.shape[0]
+    finally:
+        eng.close()
