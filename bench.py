@@ -27,17 +27,41 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: BF16 dense MFMA peak
 PEAK_HBM_GBS = 8000.0            # same guide: HBM3E 8 TB/s
+# dense-layer arithmetic (include/asr_amd.h asr_precision): reported dtype and MFMA products per f32 multiply-add
+PRECISION_INFO = {
+    'f32': ('f32', 1, PEAK_F32_MFMA_TFLOPS),
+    'f32_bf16x6': ('f32 (operands split exactly into 3 bf16 terms, 6 bf16 MFMA products per k-step, f32 accumulate)', 6,
+                   PEAK_BF16_MFMA_TFLOPS),
+    'bf16x3': ('bf16x3 (2-term bf16 split, 3 MFMA products, f32 accumulate)', 3, PEAK_BF16_MFMA_TFLOPS),
+    'bf16': ('bf16 (f32 accumulate; attention, layer norms and beam search in f32)', 1, PEAK_BF16_MFMA_TFLOPS),
+}
 
 
-def bench_config(beam=10, mtl=200):
+def bench_config(beam=10, mtl=200, precision='f32'):
     from asr_amd.utils import AttrDict
     return AttrDict({
         'model': 'Transformer', 'dst_vocab_size': 3900, 'hidden_units': 1024, 'scale_embedding': True,
         'tie_embedding_and_softmax': True, 'num_blocks': 6, 'num_heads': 16, 'ff_activation': 'glu',
         'train': {'input_dim': 320},
-        'test': {'batch_size': 64, 'max_target_length': mtl, 'lp_alpha': 0.6, 'beam_size': beam, 'num_gpus': 1},
+        'test': {'batch_size': 64, 'max_target_length': mtl, 'lp_alpha': 0.6, 'beam_size': beam, 'num_gpus': 1,
+                 'precision': precision},
     })
+
+
+def measured_traffic(kernel_class, precision):
+    """HBM-side bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    collected and corrected by tools/pmc_traffic.py on this same command); None when that class was not profiled."""
+    best = None
+    pdir = os.path.join(ROOT, 'profiles')
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith('_pmc_traffic.json') and (('_' + precision + '_') in f or (precision == 'f32' and f.count('_') == 2)):
+            try:
+                best = json.load(open(os.path.join(pdir, f))).get(kernel_class, best)
+            except (OSError, ValueError):
+                pass
+    return None if best is None else best.get('traffic_bytes_per_launch')
 
 
 def synthetic_raw(n, t_raw, seed):
@@ -82,6 +106,7 @@ def main():
     ap.add_argument('--max-target-length', type=int, default=200)
     ap.add_argument('--cpu-sample-utts', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32'), choices=sorted(PRECISION_INFO))
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -98,7 +123,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
-    cfg = bench_config(args.beam, args.max_target_length)
+    cfg = bench_config(args.beam, args.max_target_length, args.precision)
     W = weights.random_init(cfg, seed=0)
     eng = Engine(cfg, local_rank)
     eng.load_weights(W)
@@ -146,12 +171,12 @@ def main():
             'metric': 'decoded audio-sec/sec (RTFx) whole node, char unit512 block6, beam=%d' % args.beam,
             'value': audio_s / elapsed, 'unit': 'audio-sec/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / max(args.steps, 1), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': PRECISION_INFO[args.precision][0], 'data': 'synthetic',
             'config': {'workload': 'char config (hidden 1024, 16 heads, 6+6 blocks, GLU 4096, tied V=3900), beam %d, '
                                    'max_target_length %d, %d x %.0f s synthetic fbank utterances per GPU per step '
                                    '(T=%d stacked frames), random-init weights, %d decode steps taken'
                                    % (args.beam, args.max_target_length, n, t_raw / 100.0, (t_raw + 2) // 3, Y.shape[1]),
-                       'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world},
+                       'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world, 'precision': args.precision},
         }
         # ---- roofline of the dominant kernel: HIP events around every launch of one extra pass ----
         eng.set_profile(True)
@@ -162,13 +187,19 @@ def main():
         dom = max(prof, key=lambda p: p['ms'])
         ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['flops'] > 0 else dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
         is_mfma = dom['flops'] > 0 and dom['name'].startswith('gemm')
+        _, nprod, mfma_peak = PRECISION_INFO[args.precision]
+        peak = mfma_peak if is_mfma else PEAK_HBM_GBS
         out['roofline'] = {
             'kernel': dom['name'], 'bound': 'mfma' if is_mfma else 'hbm', 'achieved': ach,
-            'peak': PEAK_F32_MFMA_TFLOPS if is_mfma else PEAK_HBM_GBS, 'unit': 'TFLOP/s' if is_mfma else 'GB/s',
-            'frac': ach / (PEAK_F32_MFMA_TFLOPS if is_mfma else PEAK_HBM_GBS), 'traffic': None,
+            'peak': peak, 'unit': 'TFLOP/s' if is_mfma else 'GB/s', 'frac': ach / peak,
+            'traffic': measured_traffic(dom['name'], args.precision),
             'launches': dom['launches'], 'avg_us': 1000.0 * dom['ms'] / max(dom['launches'], 1),
             'share_of_kernel_time': dom['ms'] / tot_ms,
         }
+        if is_mfma and nprod > 1:
+            # `achieved` counts ALGORITHMIC flops (2MNK); the matrix pipe executes nprod bf16 products per f32 one
+            out['roofline']['mfma_products_per_multiply'] = nprod
+            out['roofline']['executed_frac'] = nprod * ach / peak
         out['kernels'] = [{'name': p['name'], 'ms': round(p['ms'], 3), 'launches': p['launches'],
                            'tflops': round(p['flops'] / (p['ms'] * 1e-3) / 1e12, 2) if p['ms'] > 0 else 0.0,
                            'gbs': round(p['bytes'] / (p['ms'] * 1e-3) / 1e9, 1) if p['ms'] > 0 else 0.0}

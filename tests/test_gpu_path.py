@@ -145,6 +145,35 @@ def test_full_size_char_config_matches_oracle():
         eng.close()
 
 
+FULL_SIZE_CONFIGS = [
+    # BASELINE.json configs 3-5 at sizes the oracle finishes in seconds (full architecture, few utterances / steps)
+    dict(name='pinyin_V1388_beam10', cfg=dict(dst_vocab_size=1388, beam_size=10, max_target_length=7), lens=[700, 230, 410], seed=31),
+    dict(name='word_V28444_beam10', cfg=dict(dst_vocab_size=28444, beam_size=10, max_target_length=5), lens=[330, 250], seed=32),
+    dict(name='yaml_beam13', cfg=dict(dst_vocab_size=3900, beam_size=13, max_target_length=5), lens=[200, 260], seed=34),
+    dict(name='seame_V3205_30s', cfg=dict(dst_vocab_size=3205, beam_size=10, max_target_length=4), lens=[3000], seed=33),
+]
+
+
+@pytest.mark.parametrize('case', FULL_SIZE_CONFIGS, ids=[c['name'] for c in FULL_SIZE_CONFIGS])
+def test_full_size_other_configs_match_oracle(case):
+    """Pinyin / word / SEAME architectures of the reference's YAML files (hidden 1024, 16 heads, 6+6 blocks, GLU,
+    tied): hypotheses identical to the float32 oracle, per-step logits within 1e-3 of it, ragged lengths."""
+    ocfg = O.make_config(**case['cfg'])
+    W = O.random_weights(ocfg, seed=case['seed'])
+    X = O.make_batch(O.synthetic_fbank(len(case['lens']), case['lens'], seed=case['seed'] + 100))
+    eng = _engine(ocfg, W)
+    try:
+        Y32, tr32, _ = _oracle_decode(X, W, ocfg, np.float32, 'kv')
+        Y, tr = eng.decode_trace(X, Y32.shape[1])
+        for s in range(Y32.shape[1]):
+            assert rel_err(tr['logits'][s], tr32['logits'][s]) < LOGIT_TOL
+            assert np.array_equal(tr['tokens'][s], tr32['tokens'][s]), 'step %d tokens' % s
+            assert np.array_equal(tr['parents'][s], tr32['parents'][s]), 'step %d parents' % s
+        assert np.array_equal(Y, Y32)
+    finally:
+        eng.close()
+
+
 def test_full_size_batch64_properties():
     """BASELINE config 2 at full size (64 x 10 s, beam 10, max_target_length 200): properties that need no
     oracle run -- determinism, row independence, range, and the loop-length rule (Q7)."""
