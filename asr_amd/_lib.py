@@ -83,6 +83,7 @@ def _load():
         'asr_get_profile': (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), i64p,
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), i32p]),
         'asr_device_bytes': (i64, [vp]),
+        'asr_crc32c': (C.c_uint32, [vp, i64, C.c_uint32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -1170,4 +1170,34 @@ int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, 
 
 int64_t asr_device_bytes(const asr_handle* h) { return h ? h->dev_bytes : 0; }
 
+// crc32c (Castagnoli), slicing-by-8 on the host: the tensor / block checksum of TF-V2 checkpoints
+uint32_t asr_crc32c(const void* data, int64_t n, uint32_t crc)
+{
+    static uint32_t T[8][256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int s = 1; s < 8; ++s) T[s][i] = (T[s - 1][i] >> 8) ^ T[0][T[s - 1][i] & 0xFF];
+        init = true;
+    }
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    uint32_t c = ~crc;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^
+            T[3][hi & 0xFF] ^ T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n-- > 0) c = T[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return ~c;
+}
+
 }  // extern "C"

@@ -162,6 +162,11 @@ int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, 
 /* Device-memory footprint of the handle in bytes (weights + caches + workspaces). */
 int64_t asr_device_bytes(const asr_handle* h);
 
+/* Host utility, no GPU involved: crc32c (Castagnoli) continued from `crc` (0 to start).  The checksum TensorFlow
+ * stores per tensor and per index block in the V2 checkpoints that `saver.restore` (evaluate.py:36) reads and
+ * avg_checkpoints.py:107 writes; asr_amd/tf_bundle.py uses it to verify / write such files. */
+uint32_t asr_crc32c(const void* data, int64_t n, uint32_t crc);
+
 #ifdef __cplusplus
 }
 #endif
