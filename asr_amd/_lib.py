@@ -69,6 +69,7 @@ def _load():
         'asr_finalize_weights': (i32, [vp]),
         'asr_decode': (i32, [vp, f32p, i32, i32, i32, i32p, i64, i32p]),
         'asr_decode_dev': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32p, i64, i32p]),
+        'asr_loss': (i32, [vp, f32p, i32, i32, i32, i32p, i32, C.POINTER(C.c_double)]),
         'asr_stack_frames': (i32, [vp, f32p, i32, i32, i32, i32, i32, f32p]),
         'asr_encode': (i32, [vp, f32p, i32, i32, i32, f32p, i32p]),
         'asr_decode_trace': (i32, [vp, f32p, i32, i32, i32, i32p, i64, i32p, i32, f32p, f32p, i32p, i32p]),

@@ -66,6 +66,11 @@ hipError_t launch_add_layer_norm_done(const float* resid, const float* part, int
 hipError_t launch_embed_pe(const float* E, const int32_t* preds0, const int32_t* preds1, int preds_stride,
                            const int32_t* pos_dev, const float* pe, float mult, int rows, int hidden, float* y,
                            const int32_t* done, hipStream_t s);
+// teacher-forced decoder input: y[r] = E[shift_right(Y)[r]] * mult + pe[r % ty]; Y int32 [rows] = [n][ty]
+hipError_t launch_embed_shifted(const float* E, const int32_t* Y, int rows, int ty, int vocab, const float* pe, float mult,
+                                int hidden, float* y, hipStream_t s);
+// row_loss[r] = (Y[r] != 0) * (logsumexp(logits[r]) - logits[r][Y[r]])
+hipError_t launch_xent_rows(const float* logits, const int32_t* Y, int rows, int vocab, float* row_loss, hipStream_t s);
 // kv [n*t, 2*hidden] (k | v) -> k, v [n][heads][t][64]
 hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, float* k, float* v, hipStream_t s);
 hipError_t launch_log_softmax_topk(const float* logits, int rows, int vocab, int k, float* values,
@@ -98,6 +103,9 @@ hipError_t launch_beam_prune(const float* scores, const int32_t* finished, const
 // ---- attention (attention.hip) ---------------------------------------------------------------
 hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads,
                                     float* ctx, hipStream_t s);
+// general many-query attention: q rows [n*tq] (stride ldq), k / v rows [n*tk]; pad [n][tk] or null; causal needs tq == tk
+hipError_t launch_mha(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* pad, int causal,
+                      int n, int tq, int tk, int heads, float* ctx, hipStream_t s);
 struct SelfAttnArgs {
     const float* qkv;      // [nsplit][R][3*hidden] partial qkv projections (q | k | v), bias not yet added
     int nsplit; size_t split_stride;

@@ -24,15 +24,25 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Encoder self-attention.  grid (ceil(t/128), heads, n), 4 waves x 32 query rows.
+// Many-query attention (encoder self-attention; causal self- and cross-attention of the teacher-forced
+// decoder).  grid (ceil(tq/128), heads, n), 4 waves x 32 query rows.
 // S^T = K.Q^T is computed (keys on the MFMA row index, queries on the lane), so each lane owns one
 // query: row max / sum are in-lane over 16 registers plus one exchange with lane^32, and the S^T
 // accumulator is already the B operand of O^T += V^T.P^T (no LDS round trip for P).
-// Mask: -1e9 added to logits of padded keys (common_attention.py:202), exactly as the reference;
-// keys beyond t (tile padding only) are excluded with -inf.
+// Masks, exactly as the reference: -1e9 added to logits of padded keys (common_attention.py:202) and of
+// keys after the query when `causal` (attention_bias_lower_triangle, common_attention.py:179-190; key
+// tiles wholly after the workgroup's last query are skipped - their weights are exactly 0 in f32);
+// keys beyond tk (tile padding only) are excluded with -inf.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ pad,
-                                                                 int t, int heads, float* __restrict__ ctx)
+struct MhaArgs {
+    const float* q; const float* k; const float* v;   // row pointers of utterance 0, head 0
+    int ldq, ldk, ldv;                                // floats between consecutive rows
+    const int32_t* pad;                               // [n][tk] key padding (1 = padded) or null
+    int tq, tk, heads, causal;
+    float* ctx;                                       // [n][tq][heads*64]
+};
+
+__global__ __launch_bounds__(256) void encoder_attention_kernel(MhaArgs a)
 {
     __shared__ f32x4 Ks[32 * 16];        // [key][16-B chunk ^ (key & 15)]
     __shared__ float Vs[32 * 64];        // [key][d]
@@ -40,18 +50,23 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
     __shared__ float Os[4][32][65];
 
     const int qt = blockIdx.x, h = blockIdx.y, u = blockIdx.z;
-    const int hidden = heads * 64, ld = 3 * hidden;
+    const int heads = a.heads, hidden = heads * 64;
+    const int t = a.tq, tk = a.tk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int q0w = qt * 128 + wave * 32;
     const int q = q0w + l31;
-    const float* base = qkv + (size_t)u * t * ld;
+    const float* qbase = a.q + (size_t)u * t * a.ldq;
+    const float* kbase = a.k + (size_t)u * tk * a.ldk;
+    const float* vbase = a.v + (size_t)u * tk * a.ldv;
+    const int32_t* pad = a.pad;
+    float* ctx = a.ctx;
 
     f32x4 qf[8];
 #pragma unroll
     for (int qq = 0; qq < 8; ++qq) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (q < t) v = *reinterpret_cast<const f32x4*>(base + (size_t)q * ld + h * 64 + (2 * qq + half) * 4);
+        if (q < t) v = *reinterpret_cast<const f32x4*>(qbase + (size_t)q * a.ldq + h * 64 + (2 * qq + half) * 4);
         qf[qq] = v * 0.125f;                                   // q *= key_depth_per_head ** -0.5 (utils.py:628)
     }
 
@@ -60,24 +75,24 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int nkt = (t + 31) / 32;
+    int nkt = (tk + 31) / 32;
+    if (a.causal) nkt = min(nkt, (min(qt * 128 + 127, t - 1) >> 5) + 1);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 32;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i, row = idx >> 4, c = idx & 15;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + row < t) {
-                const float* rp = base + (size_t)(k0 + row) * ld + h * 64 + c * 4;
-                kv = *reinterpret_cast<const f32x4*>(rp + hidden);
-                vv = *reinterpret_cast<const f32x4*>(rp + 2 * hidden);
+            if (k0 + row < tk) {
+                kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)(k0 + row) * a.ldk + h * 64 + c * 4);
+                vv = *reinterpret_cast<const f32x4*>(vbase + (size_t)(k0 + row) * a.ldv + h * 64 + c * 4);
             }
             Ks[row * 16 + (c ^ (row & 15))] = kv;
             reinterpret_cast<f32x4*>(Vs)[row * 16 + c] = vv;
         }
         if (tid < 32) {
             const int kk = k0 + tid;
-            Bias[tid] = (kk >= t) ? -INFINITY : (pad[(size_t)u * t + kk] ? -1e9f : 0.0f);
+            Bias[tid] = (kk >= tk) ? -INFINITY : ((pad && pad[(size_t)u * tk + kk]) ? -1e9f : 0.0f);
         }
         __syncthreads();
 
@@ -94,7 +109,9 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float* __r
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = s[r] + Bias[(r & 3) + 8 * (r >> 2) + 4 * half];
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            s[r] = s[r] + Bias[kl];
+            if (a.causal && k0 + kl > q) s[r] += -1e9f;
             mx = fmaxf(mx, s[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -499,11 +516,20 @@ __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnA
 
 }  // namespace
 
+hipError_t launch_mha(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* pad, int causal,
+                      int n, int tq, int tk, int heads, float* ctx, hipStream_t s)
+{
+    if (n <= 0 || tq <= 0) return hipSuccess;
+    if (tk <= 0 || !q || !k || !v || !ctx || ((ldq | ldk | ldv) & 3) || (causal && tq != tk)) return hipErrorInvalidValue;
+    MhaArgs a{q, k, v, ldq, ldk, ldv, pad, tq, tk, heads, causal, ctx};
+    hipLaunchKernelGGL(encoder_attention_kernel, dim3((tq + 127) / 128, heads, n), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads, float* ctx, hipStream_t s)
 {
-    if (n <= 0 || t <= 0) return hipSuccess;
-    hipLaunchKernelGGL(encoder_attention_kernel, dim3((t + 127) / 128, heads, n), dim3(256), 0, s, qkv, pad, t, heads, ctx);
-    return hipGetLastError();
+    const int hidden = heads * 64;
+    return launch_mha(qkv, 3 * hidden, qkv + hidden, 3 * hidden, qkv + 2 * hidden, 3 * hidden, pad, 0, n, t, t, heads, ctx, s);
 }
 
 size_t self_attention_lds_bytes(int k, int lds_stride)

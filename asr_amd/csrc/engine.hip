@@ -921,6 +921,68 @@ int asr_decode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, i
     return asr_decode_trace(h, X, n, t, d, Y, y_capacity, len_out, 0, nullptr, nullptr, nullptr, nullptr);
 }
 
+// Replaces Evaluator.loss (evaluate.py:49-50): sess.run(model.loss_sum) for one tower = encoder, teacher-forced
+// decoder_impl on shift_right(Y) (model.py:171,492-557) and test_loss (model.py:350-360).
+int asr_loss(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, const int32_t* Y, int32_t ty, double* loss_sum)
+{
+    if (!h || !loss_sum || (n > 0 && (!X || !Y))) return h ? fail(h, ASR_ERR_ARG, "null argument") : ASR_ERR_ARG;
+    *loss_sum = 0.0;
+    if (!h->finalized) return fail(h, ASR_ERR_STATE, "asr_finalize_weights has not succeeded on this handle");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = check_xshape(h, n, t, d))) return rc;
+    if (n == 0) return ASR_OK;                                                  // model.py:184-187: loss 0.0
+    if (ty < 1 || ty > 16384) return fail(h, ASR_ERR_ARG, "target length must be in 1..16384");
+    if ((rc = ensure_encoder_capacity(h, n, t))) return rc;
+    if ((rc = ensure_pe(h, std::max(t, ty)))) return rc;
+    hipStream_t s = h->stream;
+    const int H = h->H, F = h->F, M = n * t, Md = n * ty;
+    const size_t MH = (size_t)Md * H;
+    struct Tmp {                                                                // per-call workspaces, released on return
+        asr_handle* h; std::vector<void*> p;
+        ~Tmp() { for (void* q : p) dev_free(h, q); }
+    } tmp{h, {}};
+    auto getf = [&](float** out, size_t count) { int r = dev_alloc_t(h, out, count); if (!r) tmp.p.push_back(*out); return r; };
+    int32_t* dY = nullptr;
+    float *y0, *z1, *z2, *ctx, *part, *qkv, *kv, *hid, *logits, *rowl;
+    if ((rc = dev_alloc_t(h, &dY, (size_t)Md))) return rc;
+    tmp.p.push_back(dY);
+    if ((rc = getf(&y0, MH)) || (rc = getf(&z1, MH)) || (rc = getf(&z2, MH)) || (rc = getf(&ctx, MH)) || (rc = getf(&part, MH)) ||
+        (rc = getf(&qkv, 3 * MH)) || (rc = getf(&kv, (size_t)M * 2 * H)) || (rc = getf(&hid, (size_t)Md * F)) ||
+        (rc = getf(&logits, (size_t)Md * h->V)) || (rc = getf(&rowl, (size_t)Md)))
+        return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->xin, X, (size_t)M * d * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(dY, Y, (size_t)Md * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if ((rc = run_encoder(h, h->xin, n, t))) return rc;                         // -> h->x0, h->pad2
+    const float mult = h->cfg.scale_embedding ? (float)sqrt((double)H) : 1.0f;
+    HIP_TRY(h, launch_embed_shifted(h->emb, dY, Md, ty, h->V, h->pe, mult, H, y0, s));            // model.py:500-508
+    for (int l = 0; l < h->L; ++l) {
+        const DecBlock& b = h->dec[l];
+        if ((rc = gemm(h, y0, b.wqkv, b.bqkv, qkv, Md, 3 * H, H, EPI_BIAS, 1))) return rc;
+        HIP_TRY(h, launch_mha(qkv, 3 * H, qkv + H, 3 * H, qkv + 2 * H, 3 * H, nullptr, 1, n, ty, ty, h->heads, ctx, s));   // :516-529
+        if ((rc = gemm(h, ctx, b.wo, nullptr, part, Md, H, H, EPI_PARTIAL, 1))) return rc;
+        HIP_TRY(h, launch_add_layer_norm(y0, part, 1, 0, b.bo, b.ln0s, b.ln0b, nullptr, nullptr, Md, H, z1, s));
+        if ((rc = gemm(h, z1, b.wq, b.bq, part, Md, H, H, EPI_BIAS, 1))) return rc;
+        if ((rc = gemm(h, h->x0, b.wkv, b.bkv, kv, M, 2 * H, H, EPI_BIAS, 1))) return rc;
+        HIP_TRY(h, launch_mha(part, H, kv, 2 * H, kv + H, 2 * H, h->pad2, 0, n, ty, t, h->heads, ctx, s));              // :532-544
+        if ((rc = gemm(h, ctx, b.wco, nullptr, part, Md, H, H, EPI_PARTIAL, 1))) return rc;
+        HIP_TRY(h, launch_add_layer_norm(z1, part, 1, 0, b.bco, b.ln1s, b.ln1b, nullptr, nullptr, Md, H, z2, s));
+        if ((rc = gemm(h, z2, b.w1, b.b1, hid, Md, h->glu ? 2 * F : F, H, h->glu ? EPI_GLU : h->ff_epi, 1))) return rc;
+        if ((rc = gemm(h, hid, b.w2, nullptr, part, Md, H, F, EPI_PARTIAL, 1))) return rc;
+        HIP_TRY(h, launch_add_layer_norm(z2, part, 1, 0, b.b2, b.ln2s, b.ln2b, nullptr, nullptr, Md, H, y0, s));        // :547-555
+    }
+    const float* wout = h->cfg.tie_embedding_and_softmax ? h->emb_gemm : h->softmax_w;
+    if ((rc = gemm(h, y0, wout, nullptr, logits, Md, h->V, H, EPI_BIAS, 1))) return rc;            // :353-355
+    HIP_TRY(h, launch_xent_rows(logits, dY, Md, h->V, rowl, s));
+    std::vector<float> rl((size_t)Md);
+    HIP_TRY(h, hipMemcpyAsync(rl.data(), rowl, rl.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    double acc = 0.0;
+    for (float v : rl) acc += (double)v;
+    *loss_sum = acc;
+    return ASR_OK;
+}
+
 int asr_stack_frames(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, int32_t left, int32_t right, int32_t sub,
                      float* out)
 {

@@ -19,7 +19,7 @@ namespace {
 constexpr int BK = 32;   // k-depth of one LDS stage (floats)
 bool g_force_reg_stage = false;   // development / test switch (asr_gemm_force_reg_stage)
 #ifndef ASR_GEMM_DEBUG
-#define ASR_GEMM_DEBUG 0   // development only: 1 = no global loads in the loop, 2 = no LDS stores, 4 = no barrier
+#define ASR_GEMM_DEBUG 0   // development only: 1 = no global loads in the loop, 2 = no LDS stores, 4 = no barrier, 8 = loads re-read tile 0
 #endif
 
 typedef __attribute__((address_space(3))) void* LdsPtr;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, 
         constexpr int S = decltype(setc)::value;
         const int kk = k0 + lch * 4;
         const bool kok = kk < kend;
-        const int kc = kok ? kk : kbeg;
+        const int kc = (ASR_GEMM_DEBUG & 8) ? kbeg + lch * 4 : (kok ? kk : kbeg);   // debug 8: always the first tile (cache-resident)
         kvalid[S] = kok;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) ra[S][i] = *reinterpret_cast<const f32x4*>(arow[i] + kc);

@@ -299,6 +299,54 @@ __global__ __launch_bounds__(256) void embed_pe_kernel(const float* __restrict__
     }
 }
 
+// ---- teacher-forced decoder input (model.py:171 shift_right + :500-508): row r = (utterance, position p) gets
+// E[p == 0 ? 2 : Y[u][p-1]] * mult + timing signal of position p ------------------------------------------------
+__global__ __launch_bounds__(256) void embed_shifted_kernel(const float* __restrict__ E, const int32_t* __restrict__ Y, int ty,
+                                                             int vocab, const float* __restrict__ pe, float mult, int hidden,
+                                                             float* __restrict__ y)
+{
+    const int r = blockIdx.x, p = r % ty;
+    int tok = (p == 0) ? 2 : Y[r - 1];                       // utils.shift_right: <S> then the targets but the last
+    tok = min(max(tok, 0), vocab - 1);
+    const f32x4* e = reinterpret_cast<const f32x4*>(E + (size_t)tok * hidden);
+    const f32x4* pp = reinterpret_cast<const f32x4*>(pe + (size_t)p * hidden);
+    f32x4* o = reinterpret_cast<f32x4*>(y + (size_t)r * hidden);
+    for (int c = threadIdx.x; c < hidden / 4; c += 256) {
+        f32x4 v = e[c];
+        if (mult != 1.0f) v = v * mult;
+        o[c] = v + pp[c];
+    }
+}
+
+// ---- model.test_loss (model.py:350-360): per row softmax_cross_entropy_with_logits against one_hot(Y), times
+// (Y != 0); the rows are summed by the host in float64 ------------------------------------------------------------
+__global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict__ logits, const int32_t* __restrict__ Y, int vocab,
+                                                         float* __restrict__ row_loss)
+{
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (size_t)r * vocab;
+    float m = -INFINITY;
+    for (int i = tid; i < vocab; i += 256) m = fmaxf(m, x[i]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < vocab; i += 256) s += expf(x[i] - m);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const int yv = Y[r];
+        const float lse = logf((red[0] + red[1]) + (red[2] + red[3]));
+        const float xy = (yv >= 0 && yv < vocab) ? x[yv] : 0.0f;      // one_hot of an out-of-range label is all zeros
+        const float l = (yv >= 0 && yv < vocab) ? (lse - (xy - m)) : 0.0f;
+        row_loss[r] = (yv != 0) ? l : 0.0f;
+    }
+}
+
 // ---- cross-attention K/V layouts: kv [n*t][2H] -> k, v [n][heads][t][64] (head-major, so that one
 // (utterance, head) workgroup of the decode-time cross-attention streams two contiguous arrays) ----
 __global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restrict__ kv, int t, int heads,
@@ -580,6 +628,22 @@ hipError_t launch_embed_pe(const float* E, const int32_t* preds0, const int32_t*
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(embed_pe_kernel, dim3(rows), dim3(256), 0, s, E, preds0, preds1, preds_stride, pos_dev, pe, mult,
                        hidden, y, done);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_shifted(const float* E, const int32_t* Y, int rows, int ty, int vocab, const float* pe, float mult,
+                                int hidden, float* y, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    if (ty < 1 || (hidden & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(embed_shifted_kernel, dim3(rows), dim3(256), 0, s, E, Y, ty, vocab, pe, mult, hidden, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_xent_rows(const float* logits, const int32_t* Y, int rows, int vocab, float* row_loss, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(xent_rows_kernel, dim3(rows), dim3(256), 0, s, logits, Y, vocab, row_loss);
     return hipGetLastError();
 }
 

@@ -51,6 +51,23 @@ class Evaluator(object):
         """X float32 [N, Tmax, input_dim] -> int32 [N, Lmax] padded with 3 (evaluate.py:46-47)."""
         return self.model.predict(X)
 
+    def loss(self, X, Y):
+        """Sum over target tokens of the cross entropy of the teacher-forced decoder (evaluate.py:49-50)."""
+        return self.model.loss(X, Y)
+
+    def ppl(self, src_path, dst_path, batch_size):
+        """Perplexity of the targets in `dst_path` (evaluate.py:76-87)."""
+        logging.info('Calculate PPL for %s and %s.' % (src_path, dst_path))
+        token_count = 0
+        loss_sum = 0
+        for batch in self.data_reader.get_test_batches_with_target(src_path, dst_path, batch_size):
+            X, Y = batch
+            loss_sum += self.loss(X, Y)
+            token_count += np.sum(np.greater(Y, 0))
+        ppl = np.exp(loss_sum / token_count)
+        logging.info('PPL: %.4f' % ppl)
+        return ppl
+
     def translate(self, src_path, output_path, batch_size):
         logging.info('Translate %s.' % src_path)
         tmp = output_path + '.tmp'

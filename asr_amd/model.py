@@ -96,6 +96,19 @@ class Engine(object):
         _lib.check(self._h, lib.asr_decode(self._h, _lib.fptr(X), n, t, d, _lib.iptr(Y), Y.size, C.byref(ln)))
         return np.ascontiguousarray(Y.reshape(-1)[:n * ln.value].reshape(n, ln.value))
 
+    def loss(self, X, Y):
+        """== sess.run(model.loss_sum) for one tower: X float32 [n, t, d], Y int32 [n, ty] (0 = padding) -> float."""
+        X = _lib.f32(X)
+        Y = _lib.i32(Y)
+        n, t, d = X.shape
+        if n == 0:
+            return 0.0
+        if Y.ndim != 2 or Y.shape[0] != n:
+            raise ValueError('Y must be [n, ty] with the batch size of X')
+        out = C.c_double(0.0)
+        _lib.check(self._h, lib.asr_loss(self._h, _lib.fptr(X), n, t, d, _lib.iptr(Y), Y.shape[1], C.byref(out)))
+        return float(out.value)
+
     def decode_dev(self, ptr, n, t, d, raw=None):
         """Device-resident input (bench): `ptr` = device address of X [n,t,d], or with
         raw=(raw_frames, raw_dim, left, right, sub) of RAW fbank [n, raw_frames, raw_dim]."""
@@ -234,6 +247,17 @@ class Model(object):
         preds = [np.concatenate([p, np.full((p.shape[0], max_length - p.shape[1]), 3, np.int32)], axis=1)
                  for p in preds]                                                                     # :194-200
         return np.concatenate(preds, axis=0)                                                         # :201
+
+
+    def loss(self, X, Y):
+        """== sess.run(self.loss_sum, expand_feed_dict({self.src_pls: X, self.dst_pls: Y})) (model.py:168-190)."""
+        X = np.asarray(X, dtype=np.float32)
+        Y = np.asarray(Y, dtype=np.int32)
+        total = 0.0
+        for i, (a, b) in enumerate(shard_bounds(X.shape[0], self._num_towers)):
+            if b > a:
+                total += self.engines[i % len(self.engines)].loss(X[a:b], Y[a:b])
+        return total
 
 
 class Transformer(Model):

@@ -67,6 +67,47 @@ class DataReader(object):
             mask[i, :len(f)] = 0
         return batch, mask
 
+    @staticmethod
+    def _create_target_batch(sents, phone2idx):
+        """Token lists -> ids with </S> appended, unknown words -> <UNK> (1), zero-padded to the batch maximum:
+        ([N, Lmax] int32, mask) (utils.py:222-250)."""
+        indices = [[phone2idx.get(w, 1) for w in (list(sent) + [u'</S>'])] for sent in sents]
+        maxlen = max(len(x) for x in indices)
+        batch = np.zeros([len(sents), maxlen], np.int32)
+        mask = np.ones([len(sents), maxlen], dtype=np.int32)
+        for i, x in enumerate(indices):
+            batch[i, :len(x)] = x
+            mask[i, :len(x)] = 0
+        return batch, mask
+
+    def get_test_batches_with_target(self, src_path, dst_path, batch_size):
+        """(X, Y) batches for Evaluator.ppl (evaluate.py:76-87).  The reference calls this reader but does not
+        define it; this is the composition of its own pieces: the `uttid w1 w2 ...` target map of the training
+        reader (utils.py:108-116), scp order and batch size of get_test_batches (:384-403), targets through
+        _create_target_batch (:222-250).  Utterances without a target line are skipped with a warning."""
+        targets = {}
+        with codecs.open(dst_path, 'r', 'utf-8') as f:
+            for line in f:
+                parts = line.split()
+                if parts:
+                    targets[parts[0]] = parts[1:]
+        reader = zark.ArkReader(src_path)
+        feats, sents = [], []
+        while True:
+            uttid, feat, looped = reader.read_next_utt()
+            if looped:
+                break
+            if uttid not in targets:
+                logging.warning('uttid=%s has no target, skipped' % uttid)
+                continue
+            feats.append(feat)
+            sents.append(targets[uttid])
+            if len(feats) >= batch_size:
+                yield self._create_feat_batch(feats)[0], self._create_target_batch(sents, self.dst2idx)[0]
+                feats, sents = [], []
+        if feats:
+            yield self._create_feat_batch(feats)[0], self._create_target_batch(sents, self.dst2idx)[0]
+
     def get_test_batches(self, src_path, batch_size):
         """scp order, `batch_size` utterances per batch, no bucketing (utils.py:384-403)."""
         reader = zark.ArkReader(src_path)

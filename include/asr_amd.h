@@ -99,6 +99,13 @@ int asr_decode_dev(asr_handle* h, const float* X_dev, int32_t n, int32_t t, int3
                    int32_t raw_frames, int32_t raw_dim, int32_t left, int32_t right, int32_t sub,
                    int32_t* Y, int64_t y_capacity, int32_t* len_out);
 
+/* Replaces: `Evaluator.loss(X, Y)` for one device shard (evaluate.py:49-50 -> model.loss_sum, model.py:171-190):
+ * encoder, the teacher-forced decoder on shift_right(Y) (model.py:492-557; causal self-attention, cross-attention
+ * over the encoder output) and test_loss (model.py:350-360) = sum over positions with Y != 0 of the softmax cross
+ * entropy against Y.  Y int32 [n, ty], 0 = padding.  n == 0 gives 0.0 (model.py:184-187). */
+int asr_loss(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d,
+             const int32_t* Y, int32_t ty, double* loss_sum);
+
 /* Front end alone.  Replaces tf_fea_splice (+ the `sub` subsampling implied by the
  * `feats.scp.left3_sub3` inputs): feats [n_frames, dim] -> out [ceil(n_frames/sub), dim*(left+right+1)]. */
 int asr_stack_frames(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim,

@@ -513,6 +513,64 @@ def build_test_model(X, W, cfg, num_gpus=1, algo='kv', dtype=np.float32):
     return np.concatenate(preds, axis=0)
 
 
+def shift_right(Y, pad=BOS_INDEX):
+    """utils.py:518-520: decoder input = <S> followed by the targets but the last."""
+    Y = np.asarray(Y)
+    return np.concatenate([np.full_like(Y[:, :1], pad), Y[:, :-1]], axis=1)
+
+
+def decoder(dec_input, enc, W, cfg):
+    """model.py:492-557 (decoder_impl, teacher forced): causal self-attention with the additive -1e9 upper
+    triangle of attention_bias_lower_triangle (common_attention.py:179-190), cross-attention with the
+    re-detected encoder padding (:497-498)."""
+    dt = enc.dtype.type
+    nh = cfg.num_heads
+    L = dec_input.shape[1]
+    enc_pad = (np.abs(enc).sum(axis=-1) == 0.0)                             # :497
+    enc_bias = (enc_pad.astype(enc.dtype) * dt(MASK_BIAS))[:, None, None, :]
+    y = embed(dec_input, W, cfg, enc.dtype)                                 # :500-504
+    y = y + timing_signal(L, cfg.hidden_units, dtype=enc.dtype)[None]       # :507
+    lower = np.tril(np.ones((L, L), enc.dtype))
+    self_bias = (dt(MASK_BIAS) * (dt(1) - lower))[None, None]               # :513
+    for i in range(cfg.num_blocks):
+        p = 'decoder/block_%d' % i
+        y = residual(W, p + '/layer_norm', y,
+                     multihead_attention(W, p + '/decoder_self_attention', y, None, self_bias, nh))     # :516-529
+        y = residual(W, p + '/layer_norm_1', y,
+                     multihead_attention(W, p + '/decoder_vanilla_attention', y, enc, enc_bias, nh))    # :532-544
+        y = residual(W, p + '/layer_norm_2', y, ff_hidden(W, p + '/ff_hidden', y, cfg.ff_activation))   # :547-555
+    return y
+
+
+def test_loss(dec_out, Y, W, cfg):
+    """model.py:350-360: sum over positions with Y != 0 of softmax_cross_entropy_with_logits(logits, one_hot(Y))."""
+    logits = output_logits(dec_out, W, cfg)
+    z = log_softmax(logits)
+    Y = np.asarray(Y)
+    V = cfg.dst_vocab_size
+    valid = (Y >= 0) & (Y < V)                                              # one_hot of an out-of-range id is all zeros
+    picked = np.take_along_axis(z, np.clip(Y, 0, V - 1)[..., None], axis=-1)[..., 0]
+    loss = np.where(valid, -picked, 0.0)
+    return float(np.sum(loss.astype(np.float64) * (Y != 0)))
+
+
+test_loss.__test__ = False        # not a pytest test
+
+
+def loss_sum(X, Y, W, cfg, num_gpus=1, dtype=np.float32):
+    """evaluate.py:49-50 -> model.loss_sum (model.py:168-190): towers as in build_test_model, losses added."""
+    X = np.asarray(X, dtype=dtype)
+    Y = np.asarray(Y, dtype=np.int32)
+    Wc = cast_weights(W, dtype)
+    total = 0.0
+    for (a, b) in expand_shards(X.shape[0], max(num_gpus, 1)):
+        if b - a == 0:
+            continue                                                         # false_fn: 0.0 (:184-187)
+        enc, _ = encoder(X[a:b], Wc, cfg)
+        total += test_loss(decoder(shift_right(Y[a:b]), enc, Wc, cfg), Y[a:b], Wc, cfg)
+    return total
+
+
 def indices_to_words(Y, idx2word):
     """utils.py:405-417."""
     sents = []

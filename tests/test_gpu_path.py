@@ -197,3 +197,66 @@ def test_full_size_batch64_properties():
         assert np.array_equal(sub[:, :n], Y[5:7, :n])
     finally:
         eng.close()
+
+
+def _targets(n, ty, vocab, seed):
+    rng = np.random.default_rng(seed)
+    Y = rng.integers(4, vocab, (n, ty)).astype(np.int32)
+    for i in range(n):
+        ln = int(rng.integers(1, ty + 1))
+        Y[i, ln - 1] = 3                                            # </S> then PAD (0) as _create_target_batch makes them
+        Y[i, ln:] = 0
+    return Y
+
+
+LOSS_CASES = [
+    dict(name='tiny_untied', cfg=dict(), lens=(60, 90, 75), ty=7, seed=41),
+    dict(name='tiny_tied_relu', cfg=dict(tie_embedding_and_softmax=True, ff_activation='relu'), lens=(100, 40), ty=1, seed=42),
+    dict(name='mid_long_targets', cfg=dict(hidden_units=256, num_heads=4, num_blocks=3, dst_vocab_size=300), lens=(150, 200, 120, 90, 201),
+         ty=150, seed=43),
+]
+
+
+@pytest.mark.parametrize('case', LOSS_CASES, ids=[c['name'] for c in LOSS_CASES])
+def test_teacher_forced_loss_matches_oracle(case):
+    """Evaluator.loss (evaluate.py:49-50): encoder + decoder_impl on shift_right(Y) + test_loss; float tolerance 1e-4
+    relative on the summed loss (observed ~1e-6), towers add up (model.py:168-190)."""
+    from asr_amd.model import Transformer
+    ocfg = tiny_config(**case['cfg'])
+    W = O.random_weights(ocfg, seed=case['seed'], bias_scale=0.1)
+    X = tiny_inputs(case['lens'], seed=case['seed'] + 10)
+    Y = _targets(len(case['lens']), case['ty'], ocfg.dst_vocab_size, case['seed'])
+    want = O.loss_sum(X, Y, W, ocfg, dtype=np.float64)
+    eng = _engine(ocfg, W)
+    try:
+        got = eng.loss(X, Y)
+        assert abs(got - want) <= 1e-4 * abs(want), (got, want)
+        assert eng.loss(X, Y) == got                                # deterministic
+        assert eng.loss(X[:0], Y[:0]) == 0.0                        # empty shard: false_fn (model.py:184-187)
+        assert eng.loss(X, np.zeros_like(Y)) == 0.0                 # all-PAD targets carry no loss
+    finally:
+        eng.close()
+    for towers in (2, 3):
+        m = Transformer(product_config(ocfg, towers), towers, devices=[0])
+        m.build_test_model()
+        m.restore(W)
+        got_t = m.loss(X, Y)
+        want_t = O.loss_sum(X, Y, W, ocfg, num_gpus=towers, dtype=np.float64)
+        assert abs(got_t - want_t) <= 1e-4 * abs(want_t), (towers, got_t, want_t)
+        for e in m.engines:
+            e.close()
+
+
+def test_teacher_forced_loss_full_size():
+    """Char architecture (H=1024, 16 heads, 6+6 blocks, V=3900), 2 utterances, 40 target positions."""
+    ocfg = O.make_config()
+    W = O.random_weights(ocfg, seed=51)
+    X = O.make_batch(O.synthetic_fbank(2, [300, 240], seed=52))
+    Y = _targets(2, 40, 3900, 53)
+    want = O.loss_sum(X, Y, W, ocfg, dtype=np.float32)
+    eng = _engine(ocfg, W)
+    try:
+        got = eng.loss(X, Y)
+        assert abs(got - want) <= 1e-4 * abs(want), (got, want)
+    finally:
+        eng.close()

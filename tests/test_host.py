@@ -85,6 +85,32 @@ def test_ark_roundtrip_and_datareader_batching(tmp_path):
     assert dr.indices_to_words(np.array([[5, 6, 3, 7], [3, 3, 3, 3], [4, 4, 4, 4]])) == ['w1 w2', '', 'w0 w0 w0 w0']
 
 
+def test_target_batches_for_ppl(tmp_path):
+    """get_test_batches_with_target / _create_target_batch (evaluate.py:76-87; utils.py:108-116,222-250)."""
+    scp, arkf = str(tmp_path / 'feats.scp'), str(tmp_path / 'feats.ark')
+    rng = np.random.default_rng(1)
+    feats = [rng.standard_normal((t, 320)).astype(np.float32) for t in (12, 20, 15)]
+    w = ark.ArkWriter(scp)
+    for i, f in enumerate(feats):
+        w.write_next_utt(arkf, 'utt%d' % i, f)
+    w.close()
+    vocab = str(tmp_path / 'vocab.txt')
+    _write_vocab(vocab, 20)
+    text = str(tmp_path / 'text')
+    with open(text, 'w') as f:
+        f.write('utt0 w1 w2 w3\n\nutt2   w0  nosuchword\n')          # utt1 has no target; blank line ignored
+    cfg = product_config(tiny_config(dst_vocab_size=20))
+    cfg['dst_vocab'] = vocab
+    dr = DataReader(cfg)
+    Y, mask = dr._create_target_batch([['w1', 'w2'], ['w0']], dr.dst2idx)
+    assert Y.tolist() == [[5, 6, 3], [4, 3, 0]] and mask.tolist() == [[0, 0, 0], [0, 0, 1]] and Y.dtype == np.int32
+    batches = list(dr.get_test_batches_with_target(scp, text, 8))
+    assert len(batches) == 1
+    X, Yb = batches[0]
+    assert X.shape == (2, 15, 320) and np.array_equal(X[0, :12], feats[0]) and np.array_equal(X[1], feats[2])
+    assert Yb.tolist() == [[5, 6, 7, 3], [4, 1, 3, 0]]                  # unknown word -> <UNK> = 1, </S> appended, PAD 0
+
+
 def test_ark_double_and_compressed(tmp_path):
     import struct
     p = str(tmp_path / 'x.ark')
