@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
 // beyond t (block padding) get -inf.
 // ------------------------------------------------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 4 : 2)))
+void decoder_cross_attention_kernel(CrossAttnArgs a)
 {
     if (*a.done) return;
     __shared__ float wo[4][NB][64][17];
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnA
     const int g = lane >> 4, c = lane & 15;
     const int hidden = a.heads * 64, t = a.t, K = a.k;
 
-    // q fragments: split-K slabs fetched four at a time (independent loads in flight), summed in slab order
+    // q fragments: split-K slabs fetched two at a time (independent loads in flight), summed in slab order
     f32x4 qf[NB][4], qb[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) qb[db] = *reinterpret_cast<const f32x4*>(a.qbias + h * 64 + db * 16 + 4 * g);
@@ -392,16 +393,16 @@ __global__ __launch_bounds__(256) void decoder_cross_attention_kernel(CrossAttnA
         f32x4 acc4[4];
 #pragma unroll
         for (int db = 0; db < 4; ++db) acc4[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int z0 = 0; z0 < a.nsplit; z0 += 4) {
-            f32x4 t4[4][4];
+        for (int z0 = 0; z0 < a.nsplit; z0 += 2) {
+            f32x4 t4[2][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 const float* src = a.qpart + (size_t)min(z0 + j, a.nsplit - 1) * a.split_stride + off;
 #pragma unroll
                 for (int db = 0; db < 4; ++db) t4[j][db] = *reinterpret_cast<const f32x4*>(src + db * 16);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 2; ++j)
                 if (z0 + j < a.nsplit) {
 #pragma unroll
                     for (int db = 0; db < 4; ++db) acc4[db] += t4[j][db];

@@ -118,10 +118,18 @@ def main():
     from asr_amd import weights
     from asr_amd.model import Engine
 
+    # Rehearsal switch for a one-GPU box (never set by the driver): all ranks share GPU 0 and the gather runs over
+    # gloo on host tensors, so the multi-rank plumbing can be exercised where RCCL cannot (two ranks on one device).
+    rehearse = os.environ.get('ASR_BENCH_REHEARSE_ON_ONE_GPU', '') == '1'
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        if rehearse:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
     cfg = bench_config(args.beam, args.max_target_length, args.precision)
     W = weights.random_init(cfg, seed=0)
@@ -140,7 +148,8 @@ def main():
         if world > 1:      # gather the hypotheses (fixed width, padded with 3) on every rank
             buf = torch.full((n, width), 3, dtype=torch.int32)
             buf[:, :Y.shape[1]] = torch.from_numpy(Y)
-            buf = buf.cuda(local_rank)
+            if not rehearse:
+                buf = buf.cuda(local_rank)
             out = [torch.empty_like(buf) for _ in range(world)]
             dist.all_gather(out, buf)
         return Y
@@ -161,7 +170,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

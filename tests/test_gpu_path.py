@@ -40,6 +40,12 @@ CASES = [
                                          ff_activation='relu', max_target_length=30),
          lens=(150, 200, 120, 90, 201), seed=4, bias_scale=0.1, emb_scale=2.0),
     dict(name='short_T_limit', cfg=dict(beam_size=2, max_target_length=200), lens=(9, 6), seed=5, bias_scale=0.1, emb_scale=1.0),
+    # beam > 16: the two-beam-group instantiations of the decode attention kernels
+    dict(name='tiny_beam20', cfg=dict(beam_size=20, max_target_length=12), lens=(45, 70), seed=6, bias_scale=0.1, emb_scale=1.0),
+    dict(name='tiny_beam32_tied', cfg=dict(beam_size=32, tie_embedding_and_softmax=True, max_target_length=8), lens=(33,), seed=7,
+         bias_scale=0.2, emb_scale=1.0),
+    # long decode: min(T + 50, max_target_length) + 1 = 151 steps over a ragged batch
+    dict(name='tiny_long_decode', cfg=dict(beam_size=4, max_target_length=150), lens=(330, 120, 300), seed=8, bias_scale=0.1, emb_scale=1.0),
 ]
 
 
