@@ -188,28 +188,94 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, 
             }
         }
     } else {
-        // one k-tile; SET = register set that holds tile kt+1 (the other set holds tile kt+2, in flight)
+        // One k-tile; SET = register set that holds tile kt+1 (the other set holds tile kt+2, in flight).
+        // The side work of a tile - fragment reads of the next chunk, the selects + LDS stores of tile kt+1, the
+        // global loads of tile kt+3 - is dealt out ONE operation after each MFMA (an f32 MFMA occupies the pipe
+        // for 64 cycles, a side operation issues in a few), instead of in blocks between MFMA groups where it
+        // would leave the matrix pipe idle; sched_barrier pins that order.
+        constexpr int NM = 4 * MI * NI;                          // MFMAs per chunk
+        auto side_fload = [&](auto slotc, int buf, int q, int op) {   // op < MI + NI: one fragment read
+            constexpr int S = decltype(slotc)::value;
+            const int ch = 2 * q + lhalf;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                if (op == i) { const int row = wm0 + i * 32 + l31; af[S][i] = As[(buf * BM + row) * 8 + (ch ^ (row & 7))]; }
+#pragma unroll
+            for (int n = 0; n < NI; ++n)
+                if (op == MI + n) { const int row = wn0 + n * 32 + l31; bf[S][n] = Bs[(buf * BN + row) * 8 + (ch ^ (row & 7))]; }
+        };
+        auto side_lstore = [&](auto setc, int buf, int op) {     // op < A_LD + B_LD: one 16-byte LDS store
+            constexpr int S = decltype(setc)::value;
+            if (ASR_GEMM_DEBUG & 2) return;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i)
+                if (op == i) { const int row = lrow + 32 * i; As[(buf * BM + row) * 8 + (lch ^ (row & 7))] = kvalid[S] ? ra[S][i] : zero4; }
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)
+                if (op == A_LD + i) { const int row = lrow + 32 * i; Bs[(buf * BN + row) * 8 + (lch ^ (row & 7))] = kvalid[S] ? rb[S][i] : zero4; }
+        };
+        int g_kc = 0;
+        auto side_gload = [&](auto setc, int op) {               // op < A_LD + B_LD: one 16-byte global load
+            constexpr int S = decltype(setc)::value;
+            if (ASR_GEMM_DEBUG & 1) return;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i)
+                if (op == i) ra[S][i] = *reinterpret_cast<const f32x4*>(arow[i] + g_kc);
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)
+                if (op == A_LD + i) rb[S][i] = *reinterpret_cast<const f32x4*>(brow[i] + g_kc);
+        };
+        // chunk q of tile (buf): MFMAs from fragment slot q & 1, `side(n)` after the n-th MFMA
+        auto chunk = [&](auto slotc, auto&& side) {
+            constexpr int S = decltype(slotc)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int n = 0; n < NI; ++n) {
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[S][i][j], bf[S][n][j], acc[i][n], 0, 0, 0);
+                        side((j * MI + i) * NI + n);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        };
+        constexpr int NF = MI + NI, NL = A_LD + B_LD;
+        constexpr int LS_PER = (NL + 2 * (NM - NF) - 1) / (2 * (NM - NF));    // LDS stores per slot over chunks 1 and 2
         auto ktile = [&](auto setc, int kt) {
             constexpr int S = decltype(setc)::value;
+            using cS = std::integral_constant<int, S>;
             const int buf = kt & 1;
-            fload(c1{}, buf, 1);
-            __builtin_amdgcn_sched_barrier(0);     // fragment reads of chunk q+1 stay in front of the MFMAs of chunk q
-            mma(c0{});
-            __builtin_amdgcn_sched_barrier(0);
-            fload(c0{}, buf, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(c1{});
-            __builtin_amdgcn_sched_barrier(0);
-            fload(c1{}, buf, 3);
-            if (!(ASR_GEMM_DEBUG & 2)) lstore(std::integral_constant<int, S>{}, buf ^ 1);   // LDS stores of tile kt+1 complete under the MFMAs of chunk 2
-            __builtin_amdgcn_sched_barrier(0);
-            mma(c0{});
-            __builtin_amdgcn_sched_barrier(0);
+            // chunk 0: fragments of chunk 1
+            chunk(c0{}, [&](int n) { if (n < NF) side_fload(c1{}, buf, 1, n); });
+            // chunk 1: fragments of chunk 2, then the first LDS stores of tile kt+1
+            chunk(c1{}, [&](int n) {
+                if (n < NF) side_fload(c0{}, buf, 2, n);
+                else
+#pragma unroll
+                    for (int e = 0; e < LS_PER; ++e) side_lstore(cS{}, buf ^ 1, (n - NF) * LS_PER + e);
+            });
+            // chunk 2: fragments of chunk 3, then the remaining LDS stores
+            chunk(c0{}, [&](int n) {
+                if (n < NF) side_fload(c1{}, buf, 3, n);
+                else
+#pragma unroll
+                    for (int e = 0; e < LS_PER; ++e) side_lstore(cS{}, buf ^ 1, ((NM - NF) + (n - NF)) * LS_PER + e);
+            });
             if (!(ASR_GEMM_DEBUG & 4)) __syncthreads();
-            fload(c0{}, buf ^ 1, 0);
-            if (!(ASR_GEMM_DEBUG & 1)) gload(std::integral_constant<int, S>{}, kbeg + (kt + 3) * BK);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(c1{});
+            // chunk 3: first fragments of tile kt+1, then the global loads of tile kt+3 into the set just stored
+            {
+                const int k0 = kbeg + (kt + 3) * BK, kk = k0 + lch * 4;
+                const bool kok = kk < kend;
+                g_kc = kok ? kk : kbeg;
+                fload(c0{}, buf ^ 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int GL_PER = (NL + NM - 1) / NM;
+                chunk(c1{}, [&](int n) {
+#pragma unroll
+                    for (int e = 0; e < GL_PER; ++e) side_gload(cS{}, n * GL_PER + e);
+                });
+                kvalid[S] = kok;
+            }
         };
 
         // Every step is unconditional (tiles past the K range load a clamped address and are stored to LDS as

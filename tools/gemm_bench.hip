@@ -21,6 +21,10 @@ int main(int argc, char** argv)
         {"logits", 640, 3900, 1024, EPI_PARTIAL}, {"encqkv", 21376, 3072, 1024, EPI_BIAS},
         {"encglu", 21376, 8192, 1024, EPI_GLU},   {"encff2", 21376, 1024, 4096, EPI_PARTIAL},
         {"encprj", 21376, 1024, 1024, EPI_PARTIAL},
+        {"fixk32", 640, 1024, 32, EPI_PARTIAL},   {"fixk64", 640, 1024, 64, EPI_PARTIAL},
+        {"fixk128", 640, 1024, 128, EPI_PARTIAL}, {"fixk256", 640, 1024, 256, EPI_PARTIAL},
+        {"fixk512", 640, 1024, 512, EPI_PARTIAL}, {"fix8k32", 640, 8192, 32, EPI_PARTIAL},
+        {"fix8k256", 640, 8192, 256, EPI_PARTIAL},
     };
     size_t maxA = 0, maxW = 0, maxC = 0;
     for (auto& s : shapes) {
@@ -42,7 +46,7 @@ int main(int argc, char** argv)
         const bool dec = s.M <= 640;
         for (int tile = 1; tile <= 5; ++tile) {
             for (int split = 1; split <= (dec && s.epi == EPI_PARTIAL ? 16 : 1); split *= 2) {
-                if (s.K / split < 128) continue;
+                if (split > 1 && s.K / split < 128) continue;
                 if ((only_tile && tile != only_tile) || (only_split && split != only_split)) continue;
                 GemmArgs a{};
                 a.A = A; a.W = W; a.bias = s.epi == EPI_PARTIAL ? nullptr : bias; a.C = C;
