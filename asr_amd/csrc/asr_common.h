@@ -110,7 +110,7 @@ struct SelfAttnArgs {
     const float* qkv;      // [nsplit][R][3*hidden] partial qkv projections (q | k | v), bias not yet added
     int nsplit; size_t split_stride;
     const float* bias;     // [3*hidden]
-    float* kcache;         // [b][width][K][hidden] for this block: position-major, beam slot inside
+    float* kcache;         // [b][heads][width][K][64] for this block: head-major, then position, beam slot inside
     float* vcache;
     const int32_t* anc0;   // BeamState.anc[0], anc[1]
     const int32_t* anc1;

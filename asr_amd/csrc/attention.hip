@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(MhaArgs a)
 // ------------------------------------------------------------------------------------------------
 // Decoder self-attention at position `pos` (model.py:588-600 with reserve_last; no mask).
 // One workgroup per (utterance, head) serves all beams.  The beams' own k/v of position `pos` are
-// appended to the cache (slot = beam index); history position j < pos of beam b lives in slot
-// anc[b][j].  Beams of one utterance share most of their history, so beam_step_kernel keeps, per
+// appended to the cache (slot = beam index; layout [utterance][head][position][slot][64], so the rows one
+// workgroup gathers sit a few KB apart); history position j < pos of beam b lives in slot anc[b][j].  Beams of one utterance share most of their history, so beam_step_kernel keeps, per
 // utterance, the list of LIVE (position, slot) rows - rows referenced by at least one beam - and this
 // kernel streams exactly those rows once, flash-style on the exact-f32 16x16x4 MFMA (same operand
 // mapping as the cross-attention kernel below): S^T[key][beam] for all beams at once, entries whose
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
             k4 += *reinterpret_cast<const f32x4*>(bp + hidden);
             v4 += *reinterpret_cast<const f32x4*>(bp + 2 * hidden);
             q4 = q4 * 0.125f;
-            const size_t off = (((size_t)u * width + pos) * K + kb) * hidden + h * 64 + cc * 4;
+            const size_t off = ((((size_t)u * a.heads + h) * width + pos) * K + kb) * 64 + cc * 4;   // head-major cache
             *reinterpret_cast<f32x4*>(a.kcache + off) = k4;
             *reinterpret_cast<f32x4*>(a.vcache + off) = v4;
         }
@@ -278,20 +278,20 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
     // ---- live history rows, 16 per block, blocks dealt round-robin to the 4 waves; loads are branch-free
     // (clamped list index) and run one block ahead of the MFMAs
     const int nblk = (n_live + 15) >> 4;
-    const size_t head_off = (size_t)h * 64;
+    const size_t head_base = ((size_t)u * a.heads + h) * width;   // rows of this (utterance, head): [position][slot][64]
     f32x4 kf[4], vf[4];
     int ej[4], es[4];
     auto load_block = [&](int blk) {
         const int key0 = blk * 16;
         const int e = live[min(key0 + c, n_live - 1)];
-        const float* kr = a.kcache + (((size_t)u * width + (e >> 5)) * K + (e & 31)) * hidden + head_off + 4 * g;
+        const float* kr = a.kcache + ((head_base + (e >> 5)) * K + (e & 31)) * 64 + 4 * g;
 #pragma unroll
         for (int db = 0; db < 4; ++db) kf[db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = key0 + 4 * g + r;
             const int er = live[min(idx, n_live - 1)];
-            vf[r] = *reinterpret_cast<const f32x4*>(a.vcache + (((size_t)u * width + (er >> 5)) * K + (er & 31)) * hidden + head_off + 4 * c);
+            vf[r] = *reinterpret_cast<const f32x4*>(a.vcache + ((head_base + (er >> 5)) * K + (er & 31)) * 64 + 4 * c);
             ej[r] = er >> 5;
             es[r] = idx < n_live ? (er & 31) : -2;
         }

@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int BK = 32;   // k-depth of one LDS stage (floats)
-bool g_force_reg_stage = false;   // development / test switch (asr_gemm_force_reg_stage)
+bool g_force_reg_stage = false;   // development / test switch: always the general (MODE 0) main loop
 #ifndef ASR_GEMM_DEBUG
 #define ASR_GEMM_DEBUG 0   // development only: 1 = no global loads in the loop, 2 = no LDS stores, 4 = no barrier, 8 = loads re-read tile 0
 #endif
@@ -25,11 +25,13 @@ bool g_force_reg_stage = false;   // development / test switch (asr_gemm_force_r
 typedef __attribute__((address_space(3))) void* LdsPtr;
 
 
-// DMA = true: tiles are staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no
-// ds_write); needs K % 32 == 0.  DMA = false: register-staged path for any K % 4 == 0.
-template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
+// MODE 0: register-staged tiles, any K % 4 == 0 (a k-chunk past K is zeroed on its way into LDS).
+// MODE 2: the same for K % 64 == 0 (every K-slice is a whole number of k-tile PAIRS), without those selects.
+// MODE 1: tiles staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write); K % 32 == 0.
+template <int BM, int BN, int WM, int WN, int EPI, int MODE>
 __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
 {
+    constexpr bool DMA = MODE == 1, KTAIL = MODE == 0;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
@@ -107,12 +109,12 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, 
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const int row = lrow + 32 * i;
-            As[(buf * BM + row) * 8 + (lch ^ (row & 7))] = kvalid[S] ? ra[S][i] : zero4;
+            As[(buf * BM + row) * 8 + (lch ^ (row & 7))] = (!KTAIL || kvalid[S]) ? ra[S][i] : zero4;
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const int row = lrow + 32 * i;
-            Bs[(buf * BN + row) * 8 + (lch ^ (row & 7))] = kvalid[S] ? rb[S][i] : zero4;
+            Bs[(buf * BN + row) * 8 + (lch ^ (row & 7))] = (!KTAIL || kvalid[S]) ? rb[S][i] : zero4;
         }
     };
 
@@ -209,10 +211,10 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, 
             if (ASR_GEMM_DEBUG & 2) return;
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
-                if (op == i) { const int row = lrow + 32 * i; As[(buf * BM + row) * 8 + (lch ^ (row & 7))] = kvalid[S] ? ra[S][i] : zero4; }
+                if (op == i) { const int row = lrow + 32 * i; As[(buf * BM + row) * 8 + (lch ^ (row & 7))] = (!KTAIL || kvalid[S]) ? ra[S][i] : zero4; }
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
-                if (op == A_LD + i) { const int row = lrow + 32 * i; Bs[(buf * BN + row) * 8 + (lch ^ (row & 7))] = kvalid[S] ? rb[S][i] : zero4; }
+                if (op == A_LD + i) { const int row = lrow + 32 * i; Bs[(buf * BN + row) * 8 + (lch ^ (row & 7))] = (!KTAIL || kvalid[S]) ? rb[S][i] : zero4; }
         };
         int g_kc = 0;
         auto side_gload = [&](auto setc, int op) {               // op < A_LD + B_LD: one 16-byte global load
@@ -298,15 +300,16 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, 
     gemm_store_tile<EPI, MI, NI>(p, acc, m0, n0, wm0, wn0, z, lane);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
+template <int BM, int BN, int WM, int WN, int EPI, int MODE>
 hipError_t launch_tile_impl(const GemmArgs& a, hipStream_t s)
 {
     const int nt_m = (a.M + BM - 1) / BM, nt_n = (a.N + BN - 1) / BN;
     const int split = a.split_k < 1 ? 1 : a.split_k;
     int kchunk = (a.K + split - 1) / split;
-    kchunk = (kchunk + BK - 1) / BK * BK;
+    constexpr int KG = MODE == 2 ? 2 * BK : BK;       // MODE 2 runs k-tiles in pairs and has no zero tile to pad with
+    kchunk = (kchunk + KG - 1) / KG * KG;
     const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(f32x4);
-    auto kern = gemm_f32_nt_kernel<BM, BN, WM, WN, EPI, DMA>;
+    auto kern = gemm_f32_nt_kernel<BM, BN, WM, WN, EPI, MODE>;
     static bool attr_done[64] = {};   // per instantiation, per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -326,7 +329,9 @@ hipError_t launch_tile(const GemmArgs& a, hipStream_t s)
 {
     // the DMA-staged loop measures +2.5 % on 128x128 tiles and -5 % on the smaller ones
     const bool dma = BM == 128 && BN == 128 && (a.K % BK) == 0 && ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) & 15) == 0 && !g_force_reg_stage;
-    return dma ? launch_tile_impl<BM, BN, WM, WN, EPI, true>(a, s) : launch_tile_impl<BM, BN, WM, WN, EPI, false>(a, s);
+    if (dma) return launch_tile_impl<BM, BN, WM, WN, EPI, 1>(a, s);
+    if ((a.K % (2 * BK)) == 0 && !g_force_reg_stage) return launch_tile_impl<BM, BN, WM, WN, EPI, 2>(a, s);   // every production shape
+    return launch_tile_impl<BM, BN, WM, WN, EPI, 0>(a, s);
 }
 
 template <int EPI>
