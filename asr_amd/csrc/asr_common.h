@@ -73,8 +73,9 @@ hipError_t launch_embed_shifted(const float* E, const int32_t* Y, int rows, int 
 hipError_t launch_xent_rows(const float* logits, const int32_t* Y, int rows, int vocab, float* row_loss, hipStream_t s);
 // kv [n*t, 2*hidden] (k | v) -> k, v [n][heads][t][64]
 hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, float* k, float* v, hipStream_t s);
-hipError_t launch_log_softmax_topk(const float* logits, int rows, int vocab, int k, float* values,
-                                   int32_t* indices, const int32_t* done, hipStream_t s);
+// logits [nsplit][rows][vocab] split-K slabs (summed in slab order; nsplit = 1: plain logits)
+hipError_t launch_log_softmax_topk(const float* logits, int nsplit, size_t split_stride, int rows, int vocab, int k,
+                                   float* values, int32_t* indices, const int32_t* done, hipStream_t s);
 
 struct BeamState {       // device pointers; double-buffered arrays are indexed by (*pos & 1)
     float* scores[2];          // [R]

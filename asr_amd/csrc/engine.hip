@@ -46,6 +46,7 @@ struct asr_handle {
     bool glu = false;
     int ff_epi = EPI_RELU;
     int nprod = 0;                      // 0: exact f32 MFMA GEMMs; 6 / 3 / 1: bf16 planes (gemm_split.hip)
+    int logit_split = 1;                // K slices of the logits GEMM (their slabs are summed by the top-k kernel)
     float* emb_gemm = nullptr;          // logits operand when tied: = emb (f32 mode) or its bf16 planes
     hipStream_t stream = nullptr;
     mutable std::string err;
@@ -411,7 +412,8 @@ int ensure_decoder_capacity(asr_handle* h, int n)
     rc |= dev_alloc_t(h, &h->dctx, R * H);
     rc |= dev_alloc_t(h, &h->part, (size_t)ASR_MAX_SPLITK * R * 3 * H);
     rc |= dev_alloc_t(h, &h->dhid, R * (size_t)h->F);
-    rc |= dev_alloc_t(h, &h->logits, R * (size_t)h->V);
+    h->logit_split = std::min(2, gemm_pick_split_k((int)R, h->V, (int)H, h->nprod));        // <= 2 slabs of logits
+    rc |= dev_alloc_t(h, &h->logits, 2 * R * (size_t)h->V);
     rc |= dev_alloc_t(h, &h->cand_scores, R * (size_t)h->K);
     rc |= dev_alloc_t(h, &h->cand_tokens, R * (size_t)h->K);
     for (int l = 0; l < h->L && !rc; ++l) {
@@ -559,11 +561,12 @@ int run_decode_step(asr_handle* h, int n, int t)
         }
     }
     const float* wout = h->cfg.tie_embedding_and_softmax ? h->emb_gemm : h->softmax_w;
-    int rc = gemm(h, h->y0, wout, nullptr, h->logits, R, h->V, H, EPI_BIAS, 1);                     // model.py:341
+    const int s_log = h->logit_split;
+    int rc = gemm(h, h->y0, wout, nullptr, h->logits, R, h->V, H, EPI_PARTIAL, s_log);              // model.py:341 (no bias)
     if (rc) return rc;
     {
-        ProfScope ps(h, "log_softmax_topk", 0, 4.0 * R * (double)h->V);
-        HIP_TRY(h, launch_log_softmax_topk(h->logits, R, h->V, K, h->cand_scores, h->cand_tokens, st.done, s));   // :345-346
+        ProfScope ps(h, "log_softmax_topk", 0, 4.0 * R * (double)h->V * s_log);
+        HIP_TRY(h, launch_log_softmax_topk(h->logits, s_log, (size_t)R * h->V, R, h->V, K, h->cand_scores, h->cand_tokens, st.done, s));   // :345-346
     }
     {
         ProfScope ps(h, "beam_step", 0, 0);
@@ -621,7 +624,16 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
             int32_t posd[2];
             HIP_TRY(h, hipMemcpy(posd, h->beam.pos, sizeof(posd), hipMemcpyDeviceToHost));
             if (posd[0] == s) {                                                                     // the step really ran
-                if (tr->logits) HIP_TRY(h, hipMemcpy(tr->logits + (size_t)(s - 1) * R * h->V, h->logits, (size_t)R * h->V * 4, hipMemcpyDeviceToHost));
+                if (tr->logits) {
+                    float* dst = tr->logits + (size_t)(s - 1) * R * h->V;
+                    const size_t cnt = (size_t)R * h->V;
+                    HIP_TRY(h, hipMemcpy(dst, h->logits, cnt * 4, hipMemcpyDeviceToHost));
+                    if (h->logit_split > 1) {                   // second K slice, added in slab order like the top-k kernel does
+                        std::vector<float> slab(cnt);
+                        HIP_TRY(h, hipMemcpy(slab.data(), h->logits + cnt, cnt * 4, hipMemcpyDeviceToHost));
+                        for (size_t i = 0; i < cnt; ++i) dst[i] += slab[i];
+                    }
+                }
                 if (tr->scores) HIP_TRY(h, hipMemcpy(tr->scores + (size_t)(s - 1) * R, h->beam.scores[buf], (size_t)R * 4, hipMemcpyDeviceToHost));
                 if (tr->tokens) HIP_TRY(h, hipMemcpy(tr->tokens + (size_t)(s - 1) * R, h->beam.tokens, (size_t)R * 4, hipMemcpyDeviceToHost));
                 if (tr->parents) HIP_TRY(h, hipMemcpy(tr->parents + (size_t)(s - 1) * R, h->beam.parents, (size_t)R * 4, hipMemcpyDeviceToHost));
@@ -1168,7 +1180,7 @@ int asr_op_log_softmax_topk(asr_handle* h, const float* logits, int32_t rows, in
     HIP_TRY(h, tb.up(&dl, logits, (size_t)rows * vocab, s));
     HIP_TRY(h, tb.up<float>(&dv, nullptr, (size_t)rows * k, s));
     HIP_TRY(h, tb.up<int32_t>(&di, nullptr, (size_t)rows * k, s));
-    HIP_TRY(h, launch_log_softmax_topk(dl, rows, vocab, k, dv, di, nullptr, s));
+    HIP_TRY(h, launch_log_softmax_topk(dl, 1, 0, rows, vocab, k, dv, di, nullptr, s));
     HIP_TRY(h, hipMemcpyAsync(values, dv, (size_t)rows * k * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(indices, di, (size_t)rows * k * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));

@@ -12,6 +12,7 @@
 #include "asr_common.h"
 #include "gemm_epilogue.h"
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -22,16 +23,15 @@ bool g_force_reg_stage = false;   // development / test switch: always the gener
 #define ASR_GEMM_DEBUG 0   // development only: 1 = no global loads in the loop, 2 = no LDS stores, 4 = no barrier, 8 = loads re-read tile 0
 #endif
 
-typedef __attribute__((address_space(3))) void* LdsPtr;
-
 
 // MODE 0: register-staged tiles, any K % 4 == 0 (a k-chunk past K is zeroed on its way into LDS).
 // MODE 2: the same for K % 64 == 0 (every K-slice is a whole number of k-tile PAIRS), without those selects.
-// MODE 1: tiles staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write); K % 32 == 0.
+// (A variant that staged tiles with global_load_lds_dwordx4, swizzle applied on the source address, measured
+// within +-3 % of this register-staged loop at every tile size and was dropped.)
 template <int BM, int BN, int WM, int WN, int EPI, int MODE>
 __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
 {
-    constexpr bool DMA = MODE == 1, KTAIL = MODE == 0;
+    constexpr bool KTAIL = MODE == 0;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
@@ -147,49 +147,7 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(GemmArgs p, int nt_m, 
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
 
-    if constexpr (DMA) {
-        // One glds wave-instruction fills 8 rows x 128 B of the LDS image, lane-linear: lane l lands on
-        // chunk position l&7 of row l>>3, so it fetches the source chunk (l&7)^(l>>3) - the XOR swizzle
-        // is applied on the global address.  Tiles past the K range re-read tile 0 (never consumed).
-        [[maybe_unused]] const int src_ch = ((lane & 7) ^ (lane >> 3)) * 4;
-        auto glds = [&](int buf, int k0) {
-#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the kernel's stub; it cannot parse the LDS address-space cast)
-            const int kc = (k0 < kend ? k0 : kbeg) + src_ch;
-#pragma unroll
-            for (int i = 0; i < A_LD; ++i)
-                __builtin_amdgcn_global_load_lds(arow[i] + kc, (LdsPtr)(As + (buf * BM + 32 * i + wave * 8) * 8), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < B_LD; ++i)
-                __builtin_amdgcn_global_load_lds(brow[i] + kc, (LdsPtr)(Bs + (buf * BN + 32 * i + wave * 8) * 8), 16, 0, 0);
-#endif
-        };
-        if (nk > 0) {
-            glds(0, kbeg);
-            __syncthreads();                     // drains the DMA (vmcnt) and publishes the tile
-            glds(1, kbeg + BK);
-            fload(c0{}, 0, 0);
-            for (int kt = 0; kt < nk; ++kt) {
-                const int buf = kt & 1;
-                fload(c1{}, buf, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(c0{});
-                __builtin_amdgcn_sched_barrier(0);
-                fload(c0{}, buf, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(c1{});
-                __builtin_amdgcn_sched_barrier(0);
-                fload(c1{}, buf, 3);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(c0{});
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();                 // tile kt+1 has landed; every wave holds its last fragments of tile kt
-                fload(c0{}, buf ^ 1, 0);
-                glds(buf, kbeg + (kt + 2) * BK); // refill the buffer just released
-                __builtin_amdgcn_sched_barrier(0);
-                mma(c1{});
-            }
-        }
-    } else {
+    {
         // One k-tile; SET = register set that holds tile kt+1 (the other set holds tile kt+2, in flight).
         // The side work of a tile - fragment reads of the next chunk, the selects + LDS stores of tile kt+1, the
         // global loads of tile kt+3 - is dealt out ONE operation after each MFMA (an f32 MFMA occupies the pipe
@@ -327,9 +285,6 @@ hipError_t launch_tile_impl(const GemmArgs& a, hipStream_t s)
 template <int BM, int BN, int WM, int WN, int EPI>
 hipError_t launch_tile(const GemmArgs& a, hipStream_t s)
 {
-    // the DMA-staged loop measures +2.5 % on 128x128 tiles and -5 % on the smaller ones
-    const bool dma = BM == 128 && BN == 128 && (a.K % BK) == 0 && ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) & 15) == 0 && !g_force_reg_stage;
-    if (dma) return launch_tile_impl<BM, BN, WM, WN, EPI, 1>(a, s);
     if ((a.K % (2 * BK)) == 0 && !g_force_reg_stage) return launch_tile_impl<BM, BN, WM, WN, EPI, 2>(a, s);   // every production shape
     return launch_tile_impl<BM, BN, WM, WN, EPI, 0>(a, s);
 }

@@ -368,51 +368,72 @@ __global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restr
 // ---- model.test_output: log_softmax + top_k (model.py:345-347) -----------------------------------
 // One workgroup per row; the row lives in LDS (vocab*4 bytes).  Candidate order: value descending,
 // ties -> lower index (Q5).  z = (x - max) - log(sum exp(x - max)) exactly as tf.nn.log_softmax.
-__global__ __launch_bounds__(256) void log_softmax_topk_kernel(const float* __restrict__ logits, int vocab, int k,
-                                                                float* __restrict__ values, int32_t* __restrict__ indices,
-                                                                const int32_t* __restrict__ done)
+// The logits may arrive as split-K slabs (summed here in slab order).  Top-k: every wave extracts the k best of
+// its own quarter of the row with wave-level arg-max rounds (each lane caches the best of the elements it owns
+// and rescans only after one of them was taken), then the 4k candidates are ranked by counting.
+__global__ __launch_bounds__(256) void log_softmax_topk_kernel(const float* __restrict__ logits, int nsplit, size_t split_stride,
+                                                                int vocab, int k, float* __restrict__ values,
+                                                                int32_t* __restrict__ indices, const int32_t* __restrict__ done)
 {
     if (done && *done) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* z = reinterpret_cast<float*>(smem_raw);
     __shared__ float redv[4];
-    __shared__ int redi[4];
+    __shared__ float candv[4 * ASR_MAX_BEAM];
+    __shared__ int candi[4 * ASR_MAX_BEAM];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (size_t)r * vocab;
     float m = -INFINITY;
-    for (int i = tid; i < vocab; i += 256) { const float v = x[i]; z[i] = v; m = fmaxf(m, v); }
+    for (int i = tid; i < vocab; i += 256) {
+        float v = x[i];
+        for (int zz = 1; zz < nsplit; ++zz) v += x[zz * split_stride + i];
+        z[i] = v;
+        m = fmaxf(m, v);
+    }
     m = wave_max(m);
     if (lane == 0) redv[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
     __syncthreads();
     float s = 0.f;
-    for (int i = tid; i < vocab; i += 256) { const float sh = z[i] - m; z[i] = sh; s += expf(sh); }
+    for (int i = tid; i < vocab; i += 256) { const float sh = z[i] - m; z[i] = sh; s += expf(sh); }   // own elements only
     s = wave_sum(s);
     if (lane == 0) redv[wave] = s;
     __syncthreads();
     const float logz = logf((redv[0] + redv[1]) + (redv[2] + redv[3]));
-    __syncthreads();
-    for (int i = tid; i < vocab; i += 256) z[i] = z[i] - logz;
-    __syncthreads();
+    // from here on a thread touches only the elements it owns (i = tid + 256 j): no workgroup barrier needed
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < vocab; i += 256) { const float v = z[i] - logz; z[i] = v; if (v > bv) { bv = v; bi = i; } }   // first max kept
     for (int round = 0; round < k; ++round) {
-        float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int i = tid; i < vocab; i += 256) { const float v = z[i]; if (v > bv) { bv = v; bi = i; } }   // i ascending: first max kept
+        float wv = bv;
+        int wi = bi;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            const float ov = __shfl_xor(wv, o);
+            const int oi = __shfl_xor(wi, o);
+            if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
         }
-        if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
-            values[(size_t)r * k + round] = bv;
-            indices[(size_t)r * k + round] = bi;
-            if (bi < vocab) z[bi] = -INFINITY;
+        if (lane == 0) { candv[wave * k + round] = wv; candi[wave * k + round] = wi; }
+        if (wi == bi && bi != 0x7fffffff) {                   // this lane owned the winner: retire it, rescan own elements
+            z[bi] = -INFINITY;
+            bv = -INFINITY; bi = 0x7fffffff;
+            for (int i = tid; i < vocab; i += 256) { const float v = z[i]; if (v > bv) { bv = v; bi = i; } }
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    // rank the 4k candidates (value desc, index asc); entries with index 0x7fffffff are exhausted quarters
+    const int nc = 4 * k;
+    if (tid < nc) {
+        const float v = candv[tid];
+        const int idx = candi[tid];
+        int rank = 0;
+        for (int o = 0; o < nc; ++o) {
+            const float w = candv[o];
+            const int wi = candi[o];
+            rank += (w > v || (w == v && wi < idx)) ? 1 : 0;
+        }
+        if (rank < k && idx != 0x7fffffff) { values[(size_t)r * k + rank] = v; indices[(size_t)r * k + rank] = idx; }
     }
 }
 
@@ -654,12 +675,12 @@ hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, float*
     return hipGetLastError();
 }
 
-hipError_t launch_log_softmax_topk(const float* logits, int rows, int vocab, int k, float* values, int32_t* indices,
-                                   const int32_t* done, hipStream_t s)
+hipError_t launch_log_softmax_topk(const float* logits, int nsplit, size_t split_stride, int rows, int vocab, int k, float* values,
+                                   int32_t* indices, const int32_t* done, hipStream_t s)
 {
     if (rows <= 0) return hipSuccess;
     const size_t lds = (size_t)vocab * sizeof(float);
-    if (lds > 150 * 1024 || k < 1 || k > vocab) return hipErrorInvalidValue;
+    if (lds > 150 * 1024 || k < 1 || k > vocab || k > ASR_MAX_BEAM || nsplit < 1) return hipErrorInvalidValue;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -669,7 +690,7 @@ hipError_t launch_log_softmax_topk(const float* logits, int rows, int vocab, int
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(log_softmax_topk_kernel, dim3(rows), dim3(256), lds, s, logits, vocab, k, values, indices, done);
+    hipLaunchKernelGGL(log_softmax_topk_kernel, dim3(rows), dim3(256), lds, s, logits, nsplit, split_stride, vocab, k, values, indices, done);
     return hipGetLastError();
 }
 
