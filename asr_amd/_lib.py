@@ -71,6 +71,10 @@ def _load():
         'asr_decode_dev': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32p, i64, i32p]),
         'asr_loss': (i32, [vp, f32p, i32, i32, i32, i32p, i32, C.POINTER(C.c_double)]),
         'asr_stack_frames': (i32, [vp, f32p, i32, i32, i32, i32, i32, f32p]),
+        'asr_fea_add_delt': (i32, [vp, f32p, i32, i32, f32p]),
+        'asr_fea_cmvn_global': (i32, [vp, f32p, i32, i32, f32p, f32p, f32p]),
+        'asr_fea_cmvn_utt': (i32, [vp, f32p, i32, i32, f32p]),
+        'asr_fea_splice': (i32, [vp, f32p, i32, i32, i32, i32, i32, i32, i32, f32p]),
         'asr_encode': (i32, [vp, f32p, i32, i32, i32, f32p, i32p]),
         'asr_decode_trace': (i32, [vp, f32p, i32, i32, i32, i32p, i64, i32p, i32, f32p, f32p, i32p, i32p]),
         'asr_op_dense': (i32, [vp, f32p, f32p, f32p, i32, i32, i32, i32, f32p]),

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libasr_amd.so')
-SOURCES = ['gemm_f32.hip', 'gemm_split.hip', 'rowops.hip', 'attention.hip', 'engine.hip']
+SOURCES = ['gemm_f32.hip', 'gemm_split.hip', 'rowops.hip', 'frontend.hip', 'attention.hip', 'engine.hip']
 HEADERS = ['asr_common.h', 'gemm_epilogue.h', os.path.join('..', '..', 'include', 'asr_amd.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function']
 

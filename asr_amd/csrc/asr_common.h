@@ -31,6 +31,7 @@ struct GemmArgs {
     int epilogue;
 };
 // tile_hint: 0 = choose from the shape, 1 = 128x128, 2 = 64x64, 3 = 64x128(M x N), 4 = 128x64
+int gemm_f32_pick_tile(int M, int N, int split_k, int epilogue);
 hipError_t launch_gemm_f32(const GemmArgs& a, int tile_hint, hipStream_t s);
 // number of K-slices the decode-time projections should use for this shape (fills the chip)
 int gemm_pick_split_k(int M, int N, int K, int nprod);
@@ -48,6 +49,12 @@ hipError_t launch_frame_stack_lens(const float* raw, const int32_t* lens, int n,
                                    int right, int sub, float* out, hipStream_t s);
 hipError_t launch_frame_stack(const float* raw, int n, int raw_frames, int raw_dim, int left, int right,
                               int sub, float* out, hipStream_t s);
+// feature front end (frontend.hip; third_party/feat_convert/io/fea.py)
+hipError_t launch_fea_add_delt(const float* x, int n, int dim, float* out, hipStream_t s);
+hipError_t launch_fea_cmvn_global(const float* x, const float* mean, const float* var, int n, int dim, float* out, hipStream_t s);
+hipError_t launch_fea_cmvn_utt(const float* x, int n, int dim, float* out, hipStream_t s);
+hipError_t launch_fea_splice(const float* x, int n, int dim, int left, int right, int sub, int offset, int edge, float* out,
+                             hipStream_t s);
 hipError_t launch_pad_mask(const float* X, int rows, int d, int32_t* pad, hipStream_t s);
 // contrib layer_norm over (t, hidden) per utterance + timing signal; scratch >= n*(2*chunks+2) doubles
 hipError_t launch_input_norm_timing(const float* x, const float* gamma, const float* beta, const float* pe,

@@ -157,13 +157,13 @@ struct ProfScope {
     }
 };
 
-const char* gemm_class_name(int nprod, int M, int N, int epilogue)
+const char* gemm_class_name(int nprod, int M, int N, int epilogue, int split_k)
 {
     static std::map<std::string, std::string> interned;           // stable c_str() for ProfClass::name
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    const bool big = tiles128 >= 512;
+    const int tile = nprod == 0 ? gemm_f32_pick_tile(M, N, split_k, epilogue) : tiles128 >= 512 ? 1 : 2;
     std::string n = nprod == 0 ? "gemm_f32_nt" : nprod == 6 ? "gemm_bf16x6_nt" : nprod == 3 ? "gemm_bf16x3_nt" : "gemm_bf16_nt";
-    n += big ? "<128,128," : "<64,64,";
+    n += tile == 1 ? "<128,128," : tile == 4 ? "<128,64," : "<64,64,";
     n += epilogue == EPI_GLU ? "GLU>" : epilogue == EPI_PARTIAL ? "PARTIAL>" : epilogue == EPI_BIAS ? "BIAS>" : "ACT>";
     auto it = interned.find(n);
     if (it == interned.end()) it = interned.emplace(n, n).first;
@@ -182,7 +182,7 @@ int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float
     a.epilogue = epilogue;
     const double nout = (epilogue == EPI_GLU) ? N / 2.0 : (double)N * split_k;
     const double wbytes = h->nprod ? 2.0 * gemm_split_planes(h->nprod) : 4.0;
-    ProfScope ps(h, gemm_class_name(h->nprod, M, N, epilogue), 2.0 * M * N * (double)K,
+    ProfScope ps(h, gemm_class_name(h->nprod, M, N, epilogue, split_k), 2.0 * M * N * (double)K,
                  4.0 * ((double)M * K + (double)M * nout) + wbytes * (double)N * K);
     if (h->nprod) HIP_TRY(h, launch_gemm_split(a, h->nprod, 0, h->stream));
     else HIP_TRY(h, launch_gemm_f32(a, 0, h->stream));
@@ -706,6 +706,21 @@ struct TmpBufs {
     }
 };
 
+// copies `in_count` floats up, runs `launch(din, dout)`, copies `out_count` floats back
+template <typename F>
+int fea_roundtrip(asr_handle* h, const float* in, size_t in_count, float* out, size_t out_count, F launch)
+{
+    TmpBufs tb;
+    float *din = nullptr, *dout = nullptr;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, tb.up(&din, in, in_count, s));
+    HIP_TRY(h, tb.up(&dout, static_cast<const float*>(nullptr), out_count, s));
+    HIP_TRY(h, launch(din, dout, tb, s));
+    HIP_TRY(h, hipMemcpyAsync(out, dout, out_count * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1014,6 +1029,61 @@ int asr_stack_frames(asr_handle* h, const float* feats, int32_t n_frames, int32_
     if (dout) (void)hipFree(dout);
     HIP_TRY(h, e);
     return ASR_OK;
+}
+
+// ---- feature front end (third_party/feat_convert/io/fea.py), one utterance per call, host buffers -------------
+int asr_fea_add_delt(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, float* out)
+{
+    if (!h || !feats || !out || n_frames < 1 || dim < 1) return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t cnt = (size_t)n_frames * dim;
+    return fea_roundtrip(h, feats, cnt, out, 3 * cnt, [&](float* din, float* dout, TmpBufs&, hipStream_t s) {
+        return launch_fea_add_delt(din, n_frames, dim, dout, s);
+    });
+}
+
+int asr_fea_cmvn_global(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, const float* mean, const float* var,
+                        float* out)
+{
+    if (!h || !feats || !out || !mean || !var || n_frames < 1 || dim < 1)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t cnt = (size_t)n_frames * dim;
+    return fea_roundtrip(h, feats, cnt, out, cnt, [&](float* din, float* dout, TmpBufs& tb, hipStream_t s) {
+        float *dm = nullptr, *dv = nullptr;
+        hipError_t e = tb.up(&dm, mean, (size_t)dim, s);
+        if (e == hipSuccess) e = tb.up(&dv, var, (size_t)dim, s);
+        if (e == hipSuccess) e = launch_fea_cmvn_global(din, dm, dv, n_frames, dim, dout, s);
+        return e;
+    });
+}
+
+int asr_fea_cmvn_utt(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, float* out)
+{
+    if (!h || !feats || !out || n_frames < 1 || dim < 1) return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t cnt = (size_t)n_frames * dim;
+    return fea_roundtrip(h, feats, cnt, out, cnt, [&](float* din, float* dout, TmpBufs&, hipStream_t s) {
+        return launch_fea_cmvn_utt(din, n_frames, dim, dout, s);
+    });
+}
+
+int asr_fea_splice(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, int32_t left, int32_t right, int32_t sub,
+                   int32_t offset, int32_t edge, float* out)
+{
+    if (!h || !feats || !out || n_frames < 1 || dim < 1 || left < 0 || right < 0 || sub < 1 || offset < 0 || offset >= n_frames ||
+        (edge != 0 && edge != 1))
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t t_out = (size_t)(n_frames - offset + sub - 1) / sub;
+    return fea_roundtrip(h, feats, (size_t)n_frames * dim, out, t_out * dim * (left + right + 1),
+                         [&](float* din, float* dout, TmpBufs&, hipStream_t s) {
+                             return launch_fea_splice(din, n_frames, dim, left, right, sub, offset, edge, dout, s);
+                         });
 }
 
 int asr_encode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, float* enc_out, int32_t* pad_out)

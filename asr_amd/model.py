@@ -150,6 +150,53 @@ class Engine(object):
         _lib.check(self._h, lib.asr_stack_frames(self._h, _lib.fptr(feats), n, dim, left, right, sub, _lib.fptr(out)))
         return out
 
+    # ---- feature front end (third_party/feat_convert/io/fea.py), one utterance [frames, dim] per call ------
+    def _fea(self, feats):
+        feats = _lib.f32(feats)
+        if feats.ndim != 2 or feats.shape[0] < 1 or feats.shape[1] < 1:
+            raise ValueError('features must be a non-empty [frames, dim] matrix')
+        return feats
+
+    def fea_add_delt(self, feats):
+        """np_fea_add_delt / tf_fea_add_delt (fea.py:61-72,117-128): [n, dim] -> [n, 3*dim]."""
+        feats = self._fea(feats)
+        n, dim = feats.shape
+        out = np.empty((n, 3 * dim), np.float32)
+        _lib.check(self._h, lib.asr_fea_add_delt(self._h, _lib.fptr(feats), n, dim, _lib.fptr(out)))
+        return out
+
+    def fea_cmvn_global(self, feats, mean, var):
+        """tf_fea_cmvn_global (fea.py:130-132): (feats - mean) / var."""
+        feats = self._fea(feats)
+        n, dim = feats.shape
+        mean, var = _lib.f32(mean).reshape(-1), _lib.f32(var).reshape(-1)
+        if mean.size != dim or var.size != dim:
+            raise ValueError('mean / var must have one value per feature column')
+        out = np.empty((n, dim), np.float32)
+        _lib.check(self._h, lib.asr_fea_cmvn_global(self._h, _lib.fptr(feats), n, dim, _lib.fptr(mean), _lib.fptr(var),
+                                                    _lib.fptr(out)))
+        return out
+
+    def fea_cmvn_utt(self, feats):
+        """tf_fea_cmvn_utt (fea.py:134-140)."""
+        feats = self._fea(feats)
+        n, dim = feats.shape
+        out = np.empty((n, dim), np.float32)
+        _lib.check(self._h, lib.asr_fea_cmvn_utt(self._h, _lib.fptr(feats), n, dim, _lib.fptr(out)))
+        return out
+
+    def fea_splice(self, feats, left_num, right_num, sub=1, offset=0, edge=False):
+        """tf_fea_splice (fea.py:142-149); sub / offset keep frames offset, offset+sub, ...; edge=True repeats the
+        first / last frame as Kaldi's splice-feats does instead of padding with zeros."""
+        feats = self._fea(feats)
+        n, dim = feats.shape
+        if not 0 <= offset < n:
+            raise ValueError('offset must name a frame of the utterance')
+        out = np.empty(((n - offset + sub - 1) // sub, dim * (left_num + right_num + 1)), np.float32)
+        _lib.check(self._h, lib.asr_fea_splice(self._h, _lib.fptr(feats), n, dim, left_num, right_num, sub, offset,
+                                               1 if edge else 0, _lib.fptr(out)))
+        return out
+
     # ---- instrumentation ---------------------------------------------------------------------
     def set_profile(self, on):
         _lib.check(self._h, lib.asr_set_profile(self._h, 1 if on else 0))

@@ -111,6 +111,24 @@ int asr_loss(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d,
 int asr_stack_frames(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim,
                      int32_t left, int32_t right, int32_t sub, float* out);
 
+/* Feature front end of third_party/feat_convert/io/fea.py, one utterance per call (feats [n_frames, dim] row-major):
+ *  asr_fea_add_delt     np_fea_add_delt / tf_fea_add_delt (fea.py:61-72,117-128): out [n_frames, 3*dim] =
+ *                       feats | delta | delta-delta with the Kaldi windows of fea.py:20-52 (edge frames repeated);
+ *                       bit-identical to the float32 numpy evaluation.
+ *  asr_fea_cmvn_global  tf_fea_cmvn_global (fea.py:130-132): (feats - mean) / var, mean / var [dim] (the reference
+ *                       divides by `var` as given); bit-identical.
+ *  asr_fea_cmvn_utt     tf_fea_cmvn_utt (fea.py:134-140): per-column (x - mean) * rsqrt(E[x^2] - mean^2 + 1e-12).
+ *  asr_fea_splice       tf_fea_splice (fea.py:142-149) generalised: keeps frames offset, offset+sub, ...;
+ *                       edge = 0 pads the context with zeros (the reference), edge = 1 repeats the first / last
+ *                       frame (Kaldi splice-feats); out [ceil((n_frames-offset)/sub), dim*(left+right+1)].
+ *                       asr_stack_frames == offset 0, edge 0. */
+int asr_fea_add_delt(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, float* out);
+int asr_fea_cmvn_global(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim,
+                        const float* mean, const float* var, float* out);
+int asr_fea_cmvn_utt(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, float* out);
+int asr_fea_splice(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, int32_t left, int32_t right,
+                   int32_t sub, int32_t offset, int32_t edge, float* out);
+
 /* Parity probe.  Replaces `Model.encoder(X)` (model.py:206-209,444-490): X [n,t,d] ->
  * enc_out [n,t,hidden_units], pad_out (optional) [n,t] int32 (1 = padded frame). */
 int asr_encode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d,

@@ -46,6 +46,66 @@ def frame_stack(features, left=3, right=0, sub=3):
     return tf_fea_splice(features, left, right)[::sub]
 
 
+def splice_general(features, left_num, right_num, sub=1, offset=0, edge=False):
+    """tf_fea_splice generalised the way asr_fea_splice is: frames offset, offset+sub, ... are kept; with `edge`
+    the context frames outside the utterance repeat the first / last frame (Kaldi splice-feats) instead of
+    being zeros (fea.py:142-149)."""
+    x = np.asarray(features)
+    t, d = x.shape
+    cols = []
+    for c in range(-left_num, right_num + 1):
+        idx = np.arange(t) + c
+        inside = (idx >= 0) & (idx < t)
+        block = x[np.clip(idx, 0, t - 1)]
+        cols.append(block if edge else np.where(inside[:, None], block, np.zeros((), x.dtype)))
+    return np.concatenate(cols, axis=1)[offset::sub]
+
+
+def _shifted(x, o):
+    """x[t+o] with the frame index clamped to the utterance: what fea.py's repeated one-frame "symmetric" pads
+    (fea.py:21-22,34-37) amount to, since mirroring an already padded matrix copies the edge frame again."""
+    t = x.shape[0]
+    return x[np.clip(np.arange(t) + o, 0, t - 1)]
+
+
+def fea_delt1(features):
+    """np_kaldi_fea_delt1 / tf_kaldi_fea_delt1 (fea.py:20-31,75-86), evaluated in the dtype of `features`."""
+    x = np.asarray(features)
+    k1, k2 = x.dtype.type(0.1), x.dtype.type(0.2)
+    return (_shifted(x, 1) - _shifted(x, -1)) * k1 + (_shifted(x, 2) - _shifted(x, -2)) * k2
+
+
+def fea_delt2(features):
+    """np_kaldi_fea_delt2 / tf_kaldi_fea_delt2 (fea.py:33-52,88-107), same operation order."""
+    x = np.asarray(features)
+    f = x.dtype.type
+    s = lambda o: _shifted(x, o)
+    out = f(-0.1) * s(0) - f(0.04) * (s(-1) + s(1))
+    out = out + f(0.01) * (s(-2) + s(2))
+    out = out + f(0.04) * (((s(-3) + s(-4)) + s(4)) + s(3))
+    return out
+
+
+def fea_add_delt(features):
+    """np_fea_add_delt / tf_fea_add_delt (fea.py:61-72,117-128): static | delta | delta-delta."""
+    x = np.asarray(features)
+    return np.concatenate([x, fea_delt1(x), fea_delt2(x)], axis=1)
+
+
+def fea_cmvn_global(features, mean, var):
+    """tf_fea_cmvn_global (fea.py:130-132); note the division is by `var` itself."""
+    x = np.asarray(features)
+    return (x - np.asarray(mean, x.dtype)) / np.asarray(var, x.dtype)
+
+
+def fea_cmvn_utt(features):
+    """tf_fea_cmvn_utt (fea.py:134-140)."""
+    x = np.asarray(features)
+    mean = x.mean(axis=0)
+    var = np.square(x).mean(axis=0) - mean * mean
+    return (x - mean) * (x.dtype.type(1) / np.sqrt(var + x.dtype.type(1e-12)))
+
+
 # --------------------------------------------------------------------------------------
 # layer library
 # --------------------------------------------------------------------------------------

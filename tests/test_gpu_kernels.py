@@ -47,6 +47,66 @@ def test_frame_stack_bit_exact(L, eng, left, right, sub, n):
     assert np.array_equal(got, want)
 
 
+# ---- feature front end (third_party/feat_convert/io/fea.py) ---------------------------------------------------------
+FEA_SHAPES = [(1000, 80), (3000, 80), (301, 40), (9, 13), (4, 80), (1, 80), (2, 3)]
+
+
+@pytest.mark.parametrize('n,dim', FEA_SHAPES)
+def test_fea_add_delt_bit_exact(eng, n, dim):
+    """Delta / delta-delta windows of fea.py:20-52: same float32 operations in the same order -> identical bits."""
+    raw = np.random.default_rng(n * 131 + dim).standard_normal((n, dim)).astype(np.float32)
+    got = eng.fea_add_delt(raw)
+    want = O.fea_add_delt(raw)
+    assert got.shape == want.shape == (n, 3 * dim) and want.dtype == np.float32
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('n,dim', FEA_SHAPES)
+def test_fea_cmvn_global_bit_exact(eng, n, dim):
+    rng = np.random.default_rng(n * 7 + dim)
+    raw = (rng.standard_normal((n, dim)) * 3 + 1).astype(np.float32)
+    mean = rng.standard_normal(dim).astype(np.float32)
+    var = (rng.random(dim) + 0.5).astype(np.float32)
+    got = eng.fea_cmvn_global(raw, mean, var)
+    assert np.array_equal(got, O.fea_cmvn_global(raw, mean, var))
+
+
+@pytest.mark.parametrize('n,dim', FEA_SHAPES[:5])
+def test_fea_cmvn_utt(eng, n, dim):
+    """Floating-point reduction: within 2e-5 (relative, max-norm) of the float64 evaluation of fea.py:134-140."""
+    rng = np.random.default_rng(n + dim)
+    raw = (rng.standard_normal((n, dim)) * rng.uniform(0.5, 4, dim) + rng.uniform(-2, 2, dim)).astype(np.float32)
+    got = eng.fea_cmvn_utt(raw)
+    want = O.fea_cmvn_utt(raw.astype(np.float64))
+    assert rel_err(got, want) < 2e-5
+    assert abs(got.mean(axis=0)).max() < 1e-4 and abs(got.std(axis=0) - 1).max() < 1e-3
+
+
+@pytest.mark.parametrize('left,right,sub,offset,edge,n', [(3, 0, 3, 0, False, 1000), (3, 0, 3, 1, False, 1000),
+                                                           (3, 0, 3, 2, True, 301), (5, 5, 1, 0, True, 40),
+                                                           (2, 4, 2, 1, False, 7), (3, 3, 1, 0, True, 1),
+                                                           (0, 0, 4, 3, False, 4)])
+def test_fea_splice_bit_exact(eng, left, right, sub, offset, edge, n):
+    raw = np.random.default_rng(n).standard_normal((n, 80)).astype(np.float32)
+    got = eng.fea_splice(raw, left, right, sub=sub, offset=offset, edge=edge)
+    want = O.splice_general(raw, left, right, sub, offset, edge)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    if not edge and offset == 0:
+        assert np.array_equal(got, eng.stack_frames(raw, left, right, sub))
+
+
+def test_fea_bad_arguments(eng):
+    with pytest.raises(ValueError):
+        eng.fea_add_delt(np.zeros((0, 80), np.float32))
+    with pytest.raises(ValueError):
+        eng.fea_cmvn_global(np.zeros((3, 80), np.float32), np.zeros(79), np.ones(80))
+    with pytest.raises(ValueError):
+        eng.fea_splice(np.zeros((3, 80), np.float32), 1, 1, offset=3)
+    with pytest.raises(RuntimeError):
+        eng.fea_splice(np.zeros((3, 80), np.float32), -1, 1)
+
+
 @pytest.mark.parametrize('m,n,k,split', [(37, 50, 128, 1), (640, 3072, 1024, 1), (640, 1024, 1024, 4),
                                          (640, 1024, 4096, 8), (30, 3900, 1024, 1), (2000, 1024, 320, 1),
                                          (1, 64, 4, 1), (129, 257, 36, 2), (21376 // 8, 1024, 1024, 1)])

@@ -164,3 +164,49 @@ def test_golden_fixture():
         assert Y.tolist() == case['Y'], case['name']
         enc, _ = O.encoder(X, W, ocfg)
         assert abs(float(np.abs(enc).sum()) - case['enc_abs_sum']) < 1e-3 * case['enc_abs_sum']
+
+
+# ---- feature front end (third_party/feat_convert/io/fea.py) ---------------------------------------------------------
+def test_fea_delta_known_answers():
+    """A ramp x[t] = a*t has delta a and delta-delta 0 away from the edges (window weights: 2*0.1 + 4*0.2 = 1;
+    -0.1 - 0.08 + 0.02 + 0.16 = 0); a constant has both zero everywhere (edge frames are repeated)."""
+    t = np.arange(20, dtype=np.float64)[:, None] * np.array([[1.0, -2.5]])
+    out = O.fea_add_delt(t)
+    assert out.shape == (20, 6)
+    np.testing.assert_allclose(out[2:-2, 2:4], np.broadcast_to([1.0, -2.5], (16, 2)), atol=1e-12)
+    np.testing.assert_allclose(out[4:-4, 4:6], 0.0, atol=1e-12)
+    const = np.full((5, 3), 7.0)
+    np.testing.assert_allclose(O.fea_add_delt(const)[:, 3:], 0.0, atol=1e-12)
+    # first frame of the ramp: l1 = l2 = x[0] -> (x1 - x0)*0.1 + (x2 - x0)*0.2 = 0.5a
+    np.testing.assert_allclose(out[0, 2:4], [0.5, -1.25], atol=1e-12)
+
+
+def test_fea_delta_equals_written_out_padding():
+    """The clamped-index form used by the oracle == the repeated one-frame symmetric padding written out,
+    bit for bit in float32 (also for utterances shorter than the window)."""
+    for n in (1, 2, 3, 9, 50):
+        x = np.random.default_rng(n).standard_normal((n, 4)).astype(np.float32)
+        p = x
+        for _ in range(2):
+            p = np.pad(p, [[1, 1], [0, 0]], 'symmetric')
+        d1 = (p[3:n + 3] - p[1:n + 1]) * 0.1 + (p[4:n + 4] - p[:n]) * 0.2
+        assert d1.dtype == np.float32 and np.array_equal(d1, O.fea_delt1(x))
+        for _ in range(2):
+            p = np.pad(p, [[1, 1], [0, 0]], 'symmetric')
+        w = [p[i:n + i] for i in range(9)]
+        d2 = -0.1 * w[4] - 0.04 * (w[3] + w[5]) + 0.01 * (w[2] + w[6]) + 0.04 * (w[1] + w[0] + w[8] + w[7])
+        assert np.array_equal(d2, O.fea_delt2(x))
+
+
+def test_fea_cmvn_and_splice_known_answers():
+    x = np.random.default_rng(5).standard_normal((200, 6)) * 3 + 2
+    y = O.fea_cmvn_utt(x)
+    np.testing.assert_allclose(y.mean(axis=0), 0, atol=1e-12)
+    np.testing.assert_allclose(y.var(axis=0), 1, atol=1e-9)
+    np.testing.assert_allclose(O.fea_cmvn_global(x, np.full(6, 2.0), np.full(6, 4.0)), (x - 2) / 4)
+    z = np.arange(12, dtype=np.float32).reshape(6, 2)
+    assert np.array_equal(O.splice_general(z, 3, 0), O.tf_fea_splice(z, 3, 0))
+    assert np.array_equal(O.splice_general(z, 3, 0, sub=3), O.frame_stack(z, 3, 0, 3))
+    e = O.splice_general(z, 1, 1, edge=True)
+    assert np.array_equal(e[0], [0, 1, 0, 1, 2, 3]) and np.array_equal(e[-1], [8, 9, 10, 11, 10, 11])
+    assert np.array_equal(O.splice_general(z, 1, 0, sub=2, offset=1)[:, 2:], z[1::2])
