@@ -192,6 +192,8 @@ def main():
         eng.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
         prof = eng.get_profile()
         eng.set_profile(False)
+        overhead = [p for p in prof if p['name'].startswith('(')]
+        prof = [p for p in prof if not p['name'].startswith('(')]
         tot_ms = sum(p['ms'] for p in prof) or 1.0
         dom = max(prof, key=lambda p: p['ms'])
         ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['flops'] > 0 else dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
@@ -204,6 +206,8 @@ def main():
             'traffic': measured_traffic(dom['name'], args.precision),
             'launches': dom['launches'], 'avg_us': 1000.0 * dom['ms'] / max(dom['launches'], 1),
             'share_of_kernel_time': dom['ms'] / tot_ms,
+            # elapsed time of an EMPTY HIP-event pair, already subtracted from every bracket (asr_set_profile)
+            'event_pair_overhead_us': (1000.0 * overhead[0]['ms'] / max(overhead[0]['launches'], 1)) if overhead else None,
         }
         if is_mfma and nprod > 1:
             # `achieved` counts ALGORITHMIC flops (2MNK); the matrix pipe executes nprod bf16 products per f32 one

@@ -181,7 +181,9 @@ int asr_op_beam_step(asr_handle* h, const float* scores, const int32_t* finished
  * roofline leg and nothing else). */
 int asr_set_profile(asr_handle* h, int32_t mode);
 /* Returns up to `cap` classes accumulated since the last asr_set_profile(h, 1):
- * names[i] (static strings), total milliseconds, launch counts, algorithmic FLOPs and bytes. */
+ * names[i] (static strings), total milliseconds, launch counts, algorithmic FLOPs and bytes.
+ * asr_set_profile(h, 1) times an EMPTY event pair (median of 33) and that figure is subtracted from every
+ * bracket; the total subtracted is returned as the last class, named "(event_pair_overhead)". */
 int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, int64_t* launches,
                     double* flops, double* bytes, int32_t* n_out);
 /* Device-memory footprint of the handle in bytes (weights + caches + workspaces). */
