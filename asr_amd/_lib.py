@@ -28,7 +28,8 @@ class asr_config(C.Structure):
                 ('num_blocks', C.c_int32), ('dst_vocab_size', C.c_int32), ('ff_activation', C.c_int32),
                 ('scale_embedding', C.c_int32), ('tie_embedding_and_softmax', C.c_int32),
                 ('beam_size', C.c_int32), ('max_target_length', C.c_int32), ('lp_alpha', C.c_float),
-                ('device', C.c_int32), ('precision', C.c_int32), ('reserved', C.c_int32 * 3)]
+                ('device', C.c_int32), ('precision', C.c_int32), ('sub_batches', C.c_int32),
+                ('reserved', C.c_int32 * 2)]
 
 
 def _preload_torch_hip_runtime():

@@ -79,8 +79,13 @@ struct asr_handle {
     int32_t* cand_tokens = nullptr;
     std::vector<float*> kcache, vcache;
     BeamState beam{};
-    int32_t* done_host = nullptr;       // pinned
-    std::vector<hipEvent_t> step_events;
+    int32_t* done_host = nullptr;       // pinned, [2][max_target_length + 8]
+    std::vector<hipEvent_t> step_events;    // [2][8]
+    // The beam search of a batch may run as two independent halves (utterances are independent) on two streams,
+    // so that the launch gaps and tails of one half's kernels are filled by the other's (ASR_AMD_SUBBATCH=1 disables)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t fork_ev = nullptr;
+    int sub_batches = 0;                // 0 = automatic (two halves from 320 rows), 1 = never, 2 = whenever n >= 2
 
     // profile
     int profile = 0;
@@ -172,8 +177,9 @@ const char* gemm_class_name(int nprod, int M, int N, int epilogue, int split_k)
 }
 
 int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int epilogue,
-         int split_k)
+         int split_k, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = h->stream;
     GemmArgs a{};
     a.A = A; a.W = W; a.Wp = reinterpret_cast<const uint16_t*>(W); a.bias = bias; a.C = C;
     a.M = M; a.N = N; a.K = K;
@@ -185,8 +191,8 @@ int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float
     const double wbytes = h->nprod ? 2.0 * gemm_split_planes(h->nprod) : 4.0;
     ProfScope ps(h, gemm_class_name(h->nprod, M, N, epilogue, split_k), 2.0 * M * N * (double)K,
                  4.0 * ((double)M * K + (double)M * nout) + wbytes * (double)N * K);
-    if (h->nprod) HIP_TRY(h, launch_gemm_split(a, h->nprod, 0, h->stream));
-    else HIP_TRY(h, launch_gemm_f32(a, 0, h->stream));
+    if (h->nprod) HIP_TRY(h, launch_gemm_split(a, h->nprod, 0, stream));
+    else HIP_TRY(h, launch_gemm_f32(a, 0, stream));
     return ASR_OK;
 }
 
@@ -427,7 +433,7 @@ int ensure_decoder_capacity(asr_handle* h, int n)
         rc |= dev_alloc_t(h, &h->beam.preds[i], R * width);
         rc |= dev_alloc_t(h, &h->beam.anc[i], R * width);
     }
-    rc |= dev_alloc_t(h, &h->beam.pos, 4);
+    rc |= dev_alloc_t(h, &h->beam.pos, 16);              // pos / done / unfinished of up to two sub-batches
     rc |= dev_alloc_t(h, &h->beam.tokens, R);
     rc |= dev_alloc_t(h, &h->beam.parents, R);
     rc |= dev_alloc_t(h, &h->beam.live, R * width);
@@ -499,85 +505,177 @@ int run_cross_kv(asr_handle* h, int n, int t)
     return ASR_OK;
 }
 
-// one decode step (model.py:270-303 with decoder_with_caching_impl :559-633 restated on a K/V cache)
-int run_decode_step(asr_handle* h, int n, int t)
+// A contiguous run of utterances of the batch that is beam-searched on its own stream with its own loop state:
+// every buffer of the handle indexed by row or utterance, offset to the run's first one.
+struct DecView {
+    int n0 = 0, n = 0, idx = 0;
+    hipStream_t stream = nullptr;
+    float *y0, *z1, *z2, *dctx, *part, *dhid, *logits, *cand_scores;
+    int32_t* cand_tokens;
+    const int32_t* pad2;
+    size_t cache_off = 0, cross_off = 0;
+    BeamState beam{};
+    int32_t* done_host = nullptr;
+    hipEvent_t* events = nullptr;
+};
+
+DecView make_view(asr_handle* h, int idx, int n0, int nv, int t, hipStream_t stream)
 {
-    const int R = n * h->K, H = h->H, F = h->F, K = h->K;
-    hipStream_t s = h->stream;
-    const BeamState& st = h->beam;
-    int s_qkv, s_proj, s_ffn2;
-    decode_splits(h, R, &s_qkv, &s_proj, &s_ffn2);
-    const size_t RH = (size_t)R * H;
-    const float mult = h->cfg.scale_embedding ? (float)sqrt((double)H) : 1.0f;
-    {
-        ProfScope ps(h, "embed_pe", 0, 4.0 * R * H * 3.0);
-        HIP_TRY(h, launch_embed_pe(h->emb, st.preds[0], st.preds[1], st.width, st.pos, h->pe, mult, R, H, h->y0, st.done, s));
+    const size_t K = h->K, H = h->H, r0 = (size_t)n0 * K, width = h->beam.width;
+    DecView v;
+    v.n0 = n0; v.n = nv; v.idx = idx; v.stream = stream;
+    v.y0 = h->y0 + r0 * H; v.z1 = h->z1 + r0 * H; v.z2 = h->z2 + r0 * H; v.dctx = h->dctx + r0 * H;
+    v.part = h->part + (size_t)ASR_MAX_SPLITK * r0 * 3 * H;          // slabs of a view are contiguous, stride = its own rows
+    v.dhid = h->dhid + r0 * (size_t)h->F;
+    v.logits = h->logits + 2 * r0 * (size_t)h->V;
+    v.cand_scores = h->cand_scores + r0 * K;
+    v.cand_tokens = h->cand_tokens + r0 * K;
+    v.pad2 = h->pad2 + (size_t)n0 * t;
+    v.cache_off = r0 * width * H;                                    // [u][heads][width][K][64]
+    v.cross_off = (size_t)n0 * t * H;                                // [u][heads][t][64]
+    v.beam = h->beam;
+    for (int i = 0; i < 2; ++i) {
+        v.beam.scores[i] += r0; v.beam.finished[i] += r0; v.beam.preds[i] += r0 * width; v.beam.anc[i] += r0 * width;
     }
-    for (int l = 0; l < h->L; ++l) {
-        const DecBlock& b = h->dec[l];
-        int rc = gemm(h, h->y0, b.wqkv, nullptr, h->part, R, 3 * H, H, EPI_PARTIAL, s_qkv);
-        if (rc) return rc;
-        {
-            SelfAttnArgs a{};
-            a.qkv = h->part; a.nsplit = s_qkv; a.split_stride = 3 * RH; a.bias = b.bqkv;
-            a.kcache = h->kcache[l]; a.vcache = h->vcache[l];
-            a.anc0 = st.anc[0]; a.anc1 = st.anc[1]; a.live = st.live; a.live_cnt = st.live_cnt; a.pos = st.pos; a.done = st.done;
-            a.ctx = h->dctx; a.b = n; a.k = K; a.heads = h->heads; a.width = st.width;
-            a.lds_stride = std::min(st.width, st.limit + 2);
-            ProfScope ps(h, "decoder_self_attention", 0, 0);
-            HIP_TRY(h, launch_decoder_self_attention(a, s));
-        }
-        rc = gemm(h, h->dctx, b.wo, nullptr, h->part, R, H, H, EPI_PARTIAL, s_proj);
-        if (rc) return rc;
-        {
-            ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + s_proj));
-            HIP_TRY(h, launch_add_layer_norm_done(h->y0, h->part, s_proj, RH, b.bo, b.ln0s, b.ln0b, nullptr, nullptr, R, H,
-                                                  h->z1, st.done, s));
-        }
-        rc = gemm(h, h->z1, b.wq, nullptr, h->part, R, H, H, EPI_PARTIAL, s_proj);
-        if (rc) return rc;
-        {
-            CrossAttnArgs a{};
-            a.qpart = h->part; a.nsplit = s_proj; a.split_stride = RH; a.qbias = b.bq;
-            a.kc = h->cross_k[l]; a.v = h->cross_v[l]; a.pad2 = h->pad2; a.done = st.done;
-            a.ctx = h->dctx; a.b = n; a.k = K; a.heads = h->heads; a.t = t;
-            ProfScope ps(h, "decoder_cross_attention", 4.0 * R * (double)t * H, 4.0 * 2.0 * n * (double)t * H);
-            HIP_TRY(h, launch_decoder_cross_attention(a, s));
-        }
-        rc = gemm(h, h->dctx, b.wco, nullptr, h->part, R, H, H, EPI_PARTIAL, s_proj);
-        if (rc) return rc;
-        {
-            ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + s_proj));
-            HIP_TRY(h, launch_add_layer_norm_done(h->z1, h->part, s_proj, RH, b.bco, b.ln1s, b.ln1b, nullptr, nullptr, R, H,
-                                                  h->z2, st.done, s));
-        }
-        rc = gemm(h, h->z2, b.w1, b.b1, h->dhid, R, h->glu ? 2 * F : F, H, h->glu ? EPI_GLU : h->ff_epi, 1);
-        if (rc) return rc;
-        rc = gemm(h, h->dhid, b.w2, nullptr, h->part, R, H, F, EPI_PARTIAL, s_ffn2);
-        if (rc) return rc;
-        {
-            ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + s_ffn2));
-            HIP_TRY(h, launch_add_layer_norm_done(h->z2, h->part, s_ffn2, RH, b.b2, b.ln2s, b.ln2b, nullptr, nullptr, R, H,
-                                                  h->y0, st.done, s));
-        }
-    }
-    const float* wout = h->cfg.tie_embedding_and_softmax ? h->emb_gemm : h->softmax_w;
-    const int s_log = h->logit_split;
-    int rc = gemm(h, h->y0, wout, nullptr, h->logits, R, h->V, H, EPI_PARTIAL, s_log);              // model.py:341 (no bias)
+    v.beam.live += r0 * width; v.beam.live_cnt += n0;
+    v.beam.tokens += r0; v.beam.parents += r0;
+    v.beam.pos = h->beam.pos + 4 * idx; v.beam.done = v.beam.pos + 1; v.beam.unfinished = v.beam.pos + 2;
+    v.done_host = h->done_host + (size_t)idx * (h->cfg.max_target_length + 8);
+    v.events = h->step_events.data() + 8 * idx;
+    return v;
+}
+
+// One decode step (model.py:270-303 with decoder_with_caching_impl :559-633 restated on a K/V cache), in pieces: head
+// (embedding), per block an attention half and a feed-forward half, tail (logits, soft-max/top-k, pruning).
+struct StepCtx {
+    int n, R, s_qkv, s_proj, s_ffn2;
+    size_t RH;
+};
+
+StepCtx step_ctx(const asr_handle* h, const DecView& v)
+{
+    StepCtx c;
+    c.n = v.n; c.R = v.n * h->K; c.RH = (size_t)c.R * h->H;
+    decode_splits(h, c.R, &c.s_qkv, &c.s_proj, &c.s_ffn2);
+    return c;
+}
+
+int step_head(asr_handle* h, const DecView& v, const StepCtx& c)
+{
+    const float mult = h->cfg.scale_embedding ? (float)sqrt((double)h->H) : 1.0f;
+    const BeamState& st = v.beam;
+    ProfScope ps(h, "embed_pe", 0, 4.0 * c.R * h->H * 3.0);
+    HIP_TRY(h, launch_embed_pe(h->emb, st.preds[0], st.preds[1], st.width, st.pos, h->pe, mult, c.R, h->H, v.y0, st.done, v.stream));
+    return ASR_OK;
+}
+
+// self-attention + cross-attention sub-layers of block l (model.py:588-616): y0 -> z2
+int step_attention_half(asr_handle* h, const DecView& v, const StepCtx& c, int l, int t)
+{
+    const int n = c.n, R = c.R, H = h->H, K = h->K;
+    const size_t RH = c.RH;
+    hipStream_t s = v.stream;
+    const BeamState& st = v.beam;
+    const DecBlock& b = h->dec[l];
+    int rc = gemm(h, v.y0, b.wqkv, nullptr, v.part, R, 3 * H, H, EPI_PARTIAL, c.s_qkv, s);
     if (rc) return rc;
     {
-        ProfScope ps(h, "log_softmax_topk", 0, 4.0 * R * (double)h->V * s_log);
-        HIP_TRY(h, launch_log_softmax_topk(h->logits, s_log, (size_t)R * h->V, R, h->V, K, h->cand_scores, h->cand_tokens, st.done, s));   // :345-346
+        SelfAttnArgs a{};
+        a.qkv = v.part; a.nsplit = c.s_qkv; a.split_stride = 3 * RH; a.bias = b.bqkv;
+        a.kcache = h->kcache[l] + v.cache_off; a.vcache = h->vcache[l] + v.cache_off;
+        a.anc0 = st.anc[0]; a.anc1 = st.anc[1]; a.live = st.live; a.live_cnt = st.live_cnt; a.pos = st.pos; a.done = st.done;
+        a.ctx = v.dctx; a.b = n; a.k = K; a.heads = h->heads; a.width = st.width;
+        a.lds_stride = std::min(st.width, st.limit + 2);
+        ProfScope ps(h, "decoder_self_attention", 0, 0);
+        HIP_TRY(h, launch_decoder_self_attention(a, s));
     }
+    rc = gemm(h, v.dctx, b.wo, nullptr, v.part, R, H, H, EPI_PARTIAL, c.s_proj, s);
+    if (rc) return rc;
     {
-        ProfScope ps(h, "beam_step", 0, 0);
-        HIP_TRY(h, launch_beam_step(st, h->cand_scores, h->cand_tokens, n, K, s));                  // :280-301
+        ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + c.s_proj));
+        HIP_TRY(h, launch_add_layer_norm_done(v.y0, v.part, c.s_proj, RH, b.bo, b.ln0s, b.ln0b, nullptr, nullptr, R, H,
+                                              v.z1, st.done, s));
+    }
+    rc = gemm(h, v.z1, b.wq, nullptr, v.part, R, H, H, EPI_PARTIAL, c.s_proj, s);
+    if (rc) return rc;
+    {
+        CrossAttnArgs a{};
+        a.qpart = v.part; a.nsplit = c.s_proj; a.split_stride = RH; a.qbias = b.bq;
+        a.kc = h->cross_k[l] + v.cross_off; a.v = h->cross_v[l] + v.cross_off; a.pad2 = v.pad2; a.done = st.done;
+        a.ctx = v.dctx; a.b = n; a.k = K; a.heads = h->heads; a.t = t;
+        ProfScope ps(h, "decoder_cross_attention", 4.0 * R * (double)t * H, 4.0 * 2.0 * n * (double)t * H);
+        HIP_TRY(h, launch_decoder_cross_attention(a, s));
+    }
+    rc = gemm(h, v.dctx, b.wco, nullptr, v.part, R, H, H, EPI_PARTIAL, c.s_proj, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + c.s_proj));
+        HIP_TRY(h, launch_add_layer_norm_done(v.z1, v.part, c.s_proj, RH, b.bco, b.ln1s, b.ln1b, nullptr, nullptr, R, H,
+                                              v.z2, st.done, s));
     }
     return ASR_OK;
 }
 
-// model.py:325-336 on the host (a [n, K] problem): GNMT length penalty incl. the leading <S>, first argmax
-void finalize_host(const int32_t* preds, const float* scores, int n, int K, int width, int len, float alpha, int32_t* Y)
+// feed-forward sub-layer of block l (model.py:619-627): z2 -> y0
+int step_ffn_half(asr_handle* h, const DecView& v, const StepCtx& c, int l)
+{
+    const int R = c.R, H = h->H, F = h->F;
+    hipStream_t s = v.stream;
+    const DecBlock& b = h->dec[l];
+    int rc = gemm(h, v.z2, b.w1, b.b1, v.dhid, R, h->glu ? 2 * F : F, H, h->glu ? EPI_GLU : h->ff_epi, 1, s);
+    if (rc) return rc;
+    rc = gemm(h, v.dhid, b.w2, nullptr, v.part, R, H, F, EPI_PARTIAL, c.s_ffn2, s);
+    if (rc) return rc;
+    ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + c.s_ffn2));
+    HIP_TRY(h, launch_add_layer_norm_done(v.z2, v.part, c.s_ffn2, c.RH, b.b2, b.ln2s, b.ln2b, nullptr, nullptr, R, H,
+                                          v.y0, v.beam.done, s));
+    return ASR_OK;
+}
+
+int step_tail(asr_handle* h, const DecView& v, const StepCtx& c)
+{
+    const int R = c.R, H = h->H, K = h->K;
+    hipStream_t s = v.stream;
+    const BeamState& st = v.beam;
+    const float* wout = h->cfg.tie_embedding_and_softmax ? h->emb_gemm : h->softmax_w;
+    const int s_log = std::min(2, gemm_pick_split_k(R, h->V, H, h->nprod));                          // <= 2 slabs of logits
+    int rc = gemm(h, v.y0, wout, nullptr, v.logits, R, h->V, H, EPI_PARTIAL, s_log, s);             // model.py:341 (no bias)
+    if (rc) return rc;
+    {
+        ProfScope ps(h, "log_softmax_topk", 0, 4.0 * R * (double)h->V * s_log);
+        HIP_TRY(h, launch_log_softmax_topk(v.logits, s_log, (size_t)R * h->V, R, h->V, K, v.cand_scores, v.cand_tokens, st.done, s));   // :345-346
+    }
+    {
+        ProfScope ps(h, "beam_step", 0, 0);
+        HIP_TRY(h, launch_beam_step(st, v.cand_scores, v.cand_tokens, c.n, K, s));                  // :280-301
+    }
+    return ASR_OK;
+}
+
+// One step of every active view.  Two views run free of each other on their two streams: what was measured
+// (rocprofv3 kernel trace of both queues) is that two kernels that share the CUs each take about the sum of their solo
+// times - also an HBM-bound attention kernel beside a matrix-bound GEMM - so forcing the views half a block apart with
+// events (tried: -12 %) buys nothing; the gain of two views (+3.3 %) is the launch gaps and tails they fill for each other.
+int run_decode_step(asr_handle* h, DecView* views, const bool* active, int nviews, int t)
+{
+    for (int vi = 0; vi < nviews; ++vi) {
+        if (!active[vi]) continue;
+        const DecView& v = views[vi];
+        const StepCtx c = step_ctx(h, v);
+        int rc = step_head(h, v, c);
+        if (rc) return rc;
+        for (int l = 0; l < h->L; ++l) {
+            if ((rc = step_attention_half(h, v, c, l, t))) return rc;
+            if ((rc = step_ffn_half(h, v, c, l))) return rc;
+        }
+        if ((rc = step_tail(h, v, c))) return rc;
+    }
+    return ASR_OK;
+}
+
+// `len` = steps this run of utterances took, `ylen` >= len = row length of Y (columns len.. are padded with 3: what
+// further steps of a finished search append)
+void finalize_host(const int32_t* preds, const float* scores, int n, int K, int width, int len, float alpha, int32_t* Y, int ylen)
 {
     for (int u = 0; u < n; ++u) {
         int best = 0;
@@ -591,7 +689,8 @@ void finalize_host(const int32_t* preds, const float* scores, int n, int K, int 
             if (k == 0 || v > bestv) { bestv = v; best = k; }
         }
         const int32_t* p = preds + (size_t)(u * K + best) * width;
-        for (int j = 0; j < len; ++j) Y[(size_t)u * len + j] = p[1 + j];
+        for (int j = 0; j < len; ++j) Y[(size_t)u * ylen + j] = p[1 + j];
+        for (int j = len; j < ylen; ++j) Y[(size_t)u * ylen + j] = 3;
     }
 }
 
@@ -612,13 +711,27 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     const int K = h->K, R = n * K;
     h->beam.limit = std::min(t + 50, (int)h->cfg.max_target_length);                                // :310 (Q7)
     const int max_steps = h->beam.limit + 1;
-    HIP_TRY(h, launch_beam_init(h->beam, n, K, h->stream));
+    // Utterances are independent, so the search may run as two halves with their own loop state on two streams
+    // (kernels of one half fill the launch gaps and tails of the other's).  The joint loop of the reference ends
+    // when every utterance has finished: a half that ends earlier is padded with 3, which is what further steps
+    // append to finished beams (model.py:253) without changing their order or scores.
+    const bool want2 = h->sub_batches == 2 ? n >= 2 : (h->sub_batches == 0 && R >= 320);   // auto: each half still fills the GPU
+    const int nviews = (want2 && !tr && !h->profile) ? 2 : 1;
+    DecView views[2];
+    const int n_first = nviews == 2 ? (n + 1) / 2 : n;
+    views[0] = make_view(h, 0, 0, n_first, t, h->stream);
+    if (nviews == 2) {
+        views[1] = make_view(h, 1, n_first, n - n_first, t, h->stream2);
+        HIP_TRY(h, hipEventRecord(h->fork_ev, h->stream));                                          // encoder + cross K/V done
+        HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->fork_ev, 0));
+    }
+    for (int v = 0; v < nviews; ++v) HIP_TRY(h, launch_beam_init(views[v].beam, views[v].n, K, views[v].stream));
     constexpr int LOOKAHEAD = 3;
-    int launched = 0;
-    for (int s = 1; s <= max_steps; ++s) {
-        rc = run_decode_step(h, n, t);
+    bool ended[2] = {false, nviews < 2};
+    for (int s = 1; s <= max_steps && !(ended[0] && ended[1]); ++s) {
+        const bool active[2] = {!ended[0], !ended[1]};
+        rc = run_decode_step(h, views, active, nviews, t);
         if (rc) return rc;
-        launched = s;
         if (tr && s <= tr->steps) {
             const int buf = s & 1;
             HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -640,27 +753,39 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
                 if (tr->parents) HIP_TRY(h, hipMemcpy(tr->parents + (size_t)(s - 1) * R, h->beam.parents, (size_t)R * 4, hipMemcpyDeviceToHost));
             }
         }
-        HIP_TRY(h, hipMemcpyAsync(&h->done_host[s], h->beam.done, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipEventRecord(h->step_events[s % 8], h->stream));
-        if (s > LOOKAHEAD) {
-            const int c = s - LOOKAHEAD;
-            HIP_TRY(h, hipEventSynchronize(h->step_events[c % 8]));
-            if (h->done_host[c]) break;
+        for (int vi = 0; vi < nviews; ++vi) {
+            DecView& v = views[vi];
+            if (!active[vi]) continue;
+            HIP_TRY(h, hipMemcpyAsync(&v.done_host[s], v.beam.done, sizeof(int32_t), hipMemcpyDeviceToHost, v.stream));
+            HIP_TRY(h, hipEventRecord(v.events[s % 8], v.stream));
+            if (s > LOOKAHEAD) {
+                const int c = s - LOOKAHEAD;
+                HIP_TRY(h, hipEventSynchronize(v.events[c % 8]));
+                if (v.done_host[c]) ended[vi] = true;
+            }
         }
     }
-    (void)launched;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    int32_t posd[2] = {0, 0};
-    HIP_TRY(h, hipMemcpy(posd, h->beam.pos, sizeof(posd), hipMemcpyDeviceToHost));
-    const int len = posd[0];
-    if (!posd[1] || len < 1 || len > max_steps) return fail(h, ASR_ERR_HIP, "beam search loop ended in an inconsistent state");
+    int lens[2] = {0, 0};
+    for (int vi = 0; vi < nviews; ++vi) {
+        HIP_TRY(h, hipStreamSynchronize(views[vi].stream));
+        int32_t posd[2] = {0, 0};
+        HIP_TRY(h, hipMemcpy(posd, views[vi].beam.pos, sizeof(posd), hipMemcpyDeviceToHost));
+        lens[vi] = posd[0];
+        if (!posd[1] || lens[vi] < 1 || lens[vi] > max_steps)
+            return fail(h, ASR_ERR_HIP, "beam search loop ended in an inconsistent state");
+    }
+    const int len = std::max(lens[0], lens[1]);
     if ((int64_t)n * len > y_capacity) return fail(h, ASR_ERR_CAPACITY, "Y too small: need n * " + std::to_string(len) + " int32");
-    const int width = h->beam.width, buf = len & 1;
-    std::vector<int32_t> preds((size_t)R * width);
-    std::vector<float> scores(R);
-    HIP_TRY(h, hipMemcpy(preds.data(), h->beam.preds[buf], preds.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(scores.data(), h->beam.scores[buf], scores.size() * 4, hipMemcpyDeviceToHost));
-    finalize_host(preds.data(), scores.data(), n, K, width, len, h->cfg.lp_alpha, Y);
+    const int width = h->beam.width;
+    for (int vi = 0; vi < nviews; ++vi) {
+        const DecView& v = views[vi];
+        const int buf = lens[vi] & 1, rv = v.n * K;
+        std::vector<int32_t> preds((size_t)rv * width);
+        std::vector<float> scores(rv);
+        HIP_TRY(h, hipMemcpy(preds.data(), v.beam.preds[buf], preds.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(scores.data(), v.beam.scores[buf], scores.size() * 4, hipMemcpyDeviceToHost));
+        finalize_host(preds.data(), scores.data(), v.n, K, width, lens[vi], h->cfg.lp_alpha, Y + (size_t)v.n0 * len, len);
+    }
     *len_out = len;
     return ASR_OK;
 }
@@ -754,7 +879,8 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     if (cfg->precision < ASR_PRECISION_F32 || cfg->precision > ASR_PRECISION_BF16) return bad("unknown precision");
     if (cfg->precision != ASR_PRECISION_F32 && (cfg->input_dim & 31))
         return bad("the bf16-plane GEMM modes need input_dim % 32 == 0 (use precision = ASR_PRECISION_F32)");
-    for (int i = 0; i < 3; ++i)
+    if (cfg->sub_batches < 0 || cfg->sub_batches > 2) return bad("sub_batches must be 0 (default), 1 or 2");
+    for (int i = 0; i < 2; ++i)
         if (cfg->reserved[i]) return bad("reserved fields must be zero");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device visible (libasr_amd needs an MI355X)"; return ASR_ERR_HIP; }
@@ -783,10 +909,14 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
     if ((e = hipEventCreate(&h->pe0)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->pe1)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-    h->step_events.resize(8);
+    if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    if ((e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    if (cfg->sub_batches) h->sub_batches = cfg->sub_batches;
+    else if (const char* sb = getenv("ASR_AMD_SUBBATCH")) h->sub_batches = std::max(0, std::min(2, atoi(sb)));
+    h->step_events.resize(16);
     for (auto& ev : h->step_events)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->done_host), (size_t)(cfg->max_target_length + 8) * sizeof(int32_t), 0)) != hipSuccess)
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->done_host), (size_t)2 * (cfg->max_target_length + 8) * sizeof(int32_t), 0)) != hipSuccess)
         return hip_fail(e, "hipHostMalloc");
     h->cross_k.assign(h->L, nullptr); h->cross_v.assign(h->L, nullptr);
     h->kcache.assign(h->L, nullptr); h->vcache.assign(h->L, nullptr);
@@ -799,11 +929,14 @@ void asr_destroy(asr_handle* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     for (auto& kv : h->allocs) (void)hipFree(kv.first);
     if (h->done_host) (void)hipHostFree(h->done_host);
     for (auto ev : h->step_events) if (ev) (void)hipEventDestroy(ev);
     if (h->pe0) (void)hipEventDestroy(h->pe0);
     if (h->pe1) (void)hipEventDestroy(h->pe1);
+    if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

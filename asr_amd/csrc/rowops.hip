@@ -437,6 +437,93 @@ __global__ __launch_bounds__(256) void log_softmax_topk_kernel(const float* __re
     }
 }
 
+// Same result for rows of at most 1024*NV elements, held in REGISTERS (thread t owns the 16-byte groups t, t+256, ...):
+// no LDS image of the row, 16-byte loads of the slabs, and the arg-max rounds rescan registers.
+template <int NV>
+__global__ __launch_bounds__(256) void log_softmax_topk_reg_kernel(const float* __restrict__ logits, int nsplit, size_t split_stride,
+                                                                    int vocab, int k, float* __restrict__ values,
+                                                                    int32_t* __restrict__ indices, const int32_t* __restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ float redv[2][4];
+    __shared__ float candv[4 * ASR_MAX_BEAM];
+    __shared__ int candi[4 * ASR_MAX_BEAM];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const f32x4* x = reinterpret_cast<const f32x4*>(logits + (size_t)r * vocab);
+    const size_t stride4 = split_stride / 4;
+    const int groups = vocab >> 2;
+    float v[NV * 4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int g = tid + 256 * j;
+        const bool ok = g < groups;
+        const int gc = ok ? g : 0;                                   // branch-free, clamped address
+        f32x4 a = x[gc];
+        for (int zz = 1; zz < nsplit; ++zz) {
+            const f32x4 b = x[zz * stride4 + gc];
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[j * 4 + c] = ok ? a[c] : -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < NV * 4; ++e) m = fmaxf(m, v[e]);
+    m = wave_max(m);
+    if (lane == 0) redv[0][wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redv[0][0], redv[0][1]), fmaxf(redv[0][2], redv[0][3]));
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < NV * 4; ++e) { v[e] -= m; s += expf(v[e]); }   // exp(-inf) = 0 for the slots past the row
+    s = wave_sum(s);
+    if (lane == 0) redv[1][wave] = s;
+    __syncthreads();
+    const float logz = logf((redv[1][0] + redv[1][1]) + (redv[1][2] + redv[1][3]));
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < NV * 4; ++e) {
+        v[e] -= logz;
+        const int idx = 4 * (tid + 256 * (e >> 2)) + (e & 3);
+        if (v[e] > bv) { bv = v[e]; bi = idx; }                     // ascending index order: the first maximum is kept
+    }
+    for (int round = 0; round < k; ++round) {
+        float wv = bv;
+        int wi = bi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(wv, o);
+            const int oi = __shfl_xor(wi, o);
+            if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+        }
+        if (lane == 0) { candv[wave * k + round] = wv; candi[wave * k + round] = wi; }
+        if (wi == bi && bi != 0x7fffffff) {                         // this lane owned the winner: retire it, rescan
+            const int taken = bi;
+            bv = -INFINITY; bi = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < NV * 4; ++e) {
+                const int idx = 4 * (tid + 256 * (e >> 2)) + (e & 3);
+                if (idx == taken) v[e] = -INFINITY;
+                if (v[e] > bv) { bv = v[e]; bi = idx; }
+            }
+        }
+    }
+    __syncthreads();
+    const int nc = 4 * k;
+    if (tid < nc) {
+        const float cv = candv[tid];
+        const int idx = candi[tid];
+        int rank = 0;
+        for (int o = 0; o < nc; ++o) {
+            const float w = candv[o];
+            const int wi = candi[o];
+            rank += (w > cv || (w == cv && wi < idx)) ? 1 : 0;
+        }
+        if (rank < k && idx != 0x7fffffff) { values[(size_t)r * k + rank] = cv; indices[(size_t)r * k + rank] = idx; }
+    }
+}
+
 // ---- beam pruning (model.py:280-301) ------------------------------------------------
 // One workgroup per utterance.  K*K candidates are ranked by counting (value desc, ties -> lower
 // flat index), which reproduces a sorted tf.nn.top_k.
@@ -681,6 +768,15 @@ hipError_t launch_log_softmax_topk(const float* logits, int nsplit, size_t split
     if (rows <= 0) return hipSuccess;
     const size_t lds = (size_t)vocab * sizeof(float);
     if (lds > 150 * 1024 || k < 1 || k > vocab || k > ASR_MAX_BEAM || nsplit < 1) return hipErrorInvalidValue;
+    if ((vocab & 3) == 0 && (split_stride & 3) == 0 && vocab <= 4096 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        if (vocab <= 2048)
+            hipLaunchKernelGGL(log_softmax_topk_reg_kernel<2>, dim3(rows), dim3(256), 0, s, logits, nsplit, split_stride, vocab, k,
+                               values, indices, done);
+        else
+            hipLaunchKernelGGL(log_softmax_topk_reg_kernel<4>, dim3(rows), dim3(256), 0, s, logits, nsplit, split_stride, vocab, k,
+                               values, indices, done);
+        return hipGetLastError();
+    }
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;

@@ -47,6 +47,11 @@ class Engine(object):
             raise ValueError('unknown test.precision %r (one of %s)' % (prec, sorted(_lib.PRECISIONS)))
         c.precision = _lib.PRECISIONS[prec]
         self.precision = prec
+        # build extension: 1 = one run of kernels per batch, 2 = two independent halves on two streams, None = library default
+        sb = int(t.sub_batches or 0)
+        if sb not in (0, 1, 2):
+            raise ValueError('test.sub_batches must be 1 or 2')
+        c.sub_batches = sb
         self.cfg = c
         self.device = int(device)
         self._h = C.c_void_p()

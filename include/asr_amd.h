@@ -60,7 +60,11 @@ typedef struct asr_config {
     float   lp_alpha;                    /* test.lp_alpha                                 */
     int32_t device;                      /* HIP device ordinal this handle lives on       */
     int32_t precision;                   /* enum asr_precision (build extension; YAML key test.precision, default f32) */
-    int32_t reserved[3];                 /* must be zero                                  */
+    int32_t sub_batches;                 /* 1 = beam-search the batch as one run of kernels, 2 = as two independent halves on
+                                            two streams (same results: utterances are independent), 0 = env
+                                            ASR_AMD_SUBBATCH or automatic (two halves from 320 beam rows);
+                                            build extension, YAML key test.sub_batches */
+    int32_t reserved[2];                 /* must be zero                                  */
 } asr_config;
 
 /* Number of HIP devices visible to this process (0 when there is none or on error).  Replaces the

@@ -4,10 +4,12 @@ import numpy as np
 from oracle import asr_oracle as O
 
 
-def product_config(ocfg, num_gpus=1, precision=None):
+def product_config(ocfg, num_gpus=1, precision=None, sub_batches=None):
     """oracle Config -> the AttrDict shape the product reads from the YAML files."""
     from asr_amd.utils import AttrDict
     test_extra = {'precision': precision} if precision else {}       # build extension key (include/asr_amd.h asr_precision)
+    if sub_batches:
+        test_extra['sub_batches'] = sub_batches                      # build extension key (asr_config.sub_batches)
     return AttrDict({
         'model': 'Transformer',
         'dst_vocab_size': ocfg.dst_vocab_size,

@@ -221,7 +221,8 @@ def test_encoder_attention_mask_gives_exact_zero_weight(L, eng):
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize('rows,vocab,k', [(640, 3900, 10), (7, 50, 3), (64, 28444, 10), (5, 1388, 13), (3, 10, 10), (4, 4, 1)])
+@pytest.mark.parametrize('rows,vocab,k', [(640, 3900, 10), (7, 50, 3), (64, 28444, 10), (5, 1388, 13), (3, 10, 10), (4, 4, 1),
+                                          (9, 2048, 10), (9, 4096, 32), (3, 2052, 5), (3, 8, 8), (9, 3205, 10), (5, 4100, 10)])
 def test_log_softmax_topk(L, eng, rows, vocab, k):
     rng = np.random.default_rng(vocab)
     x = (rng.standard_normal((rows, vocab)) * 3).astype(np.float32)

@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3
 
 
-def _engine(ocfg, W, device=0):
+def _engine(ocfg, W, device=0, sub_batches=None):
     from asr_amd.model import Engine
-    e = Engine(product_config(ocfg), device)
+    e = Engine(product_config(ocfg, sub_batches=sub_batches), device)
     e.load_weights(W)
     return e
 
@@ -114,6 +114,28 @@ def test_batch_row_independence_and_empty_batch():
         assert eng.decode(np.zeros((0, 10, 320), np.float32)).shape == (0, 0)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('lens,beam,mtl', [((75, 40, 90, 33, 60, 81, 20), 3, 20), ((50, 64), 10, 12),
+                                           ((30, 30, 30, 200, 200), 4, 60), ((45,) * 9, 2, 30)])
+def test_two_half_batches_on_two_streams_give_the_same_hypotheses(lens, beam, mtl):
+    """asr_config.sub_batches = 2: the beam search runs as two independent halves with their own loop state; a half
+    that ends earlier is padded with 3 (the joint loop of model.py:305-312 ends when every utterance has)."""
+    ocfg = tiny_config(beam_size=beam, max_target_length=mtl)
+    W = O.random_weights(ocfg, seed=21, bias_scale=0.1)
+    X = tiny_inputs(lens, seed=22)
+    one, two = _engine(ocfg, W, sub_batches=1), _engine(ocfg, W, sub_batches=2)
+    try:
+        want, _, _ = _oracle_decode(X, W, ocfg, np.float32, 'kv')
+        a = one.decode(X)
+        b = two.decode(X)
+        assert np.array_equal(a, want)
+        assert b.shape == a.shape and np.array_equal(b, a)
+        assert np.array_equal(two.decode(X), b)                        # and again: state of both streams is re-initialised
+        assert np.array_equal(two.decode(X[:1]), a[:1, :two.decode(X[:1]).shape[1]])     # n = 1 falls back to one run
+    finally:
+        one.close()
+        two.close()
 
 
 def test_device_front_end_matches_host_stacking():
