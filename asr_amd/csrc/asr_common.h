@@ -22,7 +22,7 @@ enum GemmEpilogue {
 struct GemmArgs {
     const float* A;    // [M, K] row-major, leading dimension lda
     const float* W;    // [N, K] row-major ("kernel [out, in]", utils.py:551), leading dimension ldw
-    const uint16_t* Wp; // gemm_split.hip only: the same matrix as bf16 planes [planes][N][K] (W unused)
+    const uint16_t* Wp; // gemm_split.hip only: the same matrix as bf16 planes in panel order (gemm_split_weights_host; W unused)
     const float* bias; // [N] or null
     float* C;          // [M, ldc] (EPI_PARTIAL: [split_k][M][ldc])
     int M, N, K;
@@ -39,10 +39,15 @@ int gemm_pick_split_k(int M, int N, int K, int nprod);
 void gemm_force_reg_stage(bool on);
 
 // f32 GEMM on the bf16 matrix cores by operand splitting (gemm_split.hip); nprod = 6 (f32 accuracy), 3 or 1 (bf16).
-// Needs K % 32 == 0 and a.Wp = bf16 planes made by gemm_split_weights_host (gemm_split_planes(nprod) of them).
+// Needs K % 32 == 0 and a.Wp = the weight matrix as made by gemm_split_weights_host (gemm_split_planes(nprod) bf16 planes in
+// the kernel's panel order; gemm_split_weight_elems() uint16 elements).
+// tile_hint: 0 = choose from the shape, 1 = 128x128, 2 = 64x128, 5 = 160x128, 6 = 96x128 (M x N)
 hipError_t launch_gemm_split(const GemmArgs& a, int nprod, int tile_hint, hipStream_t s);
+int gemm_split_pick_tile(int M, int N, int split_k, int epilogue);
+int gemm_split_pick_split_k(int M, int N, int K, int nprod);
 int gemm_split_planes(int nprod);
-void gemm_split_weights_host(const float* w, size_t count, int nplanes, uint16_t* planes);
+size_t gemm_split_weight_elems(int n, int k, int nplanes);
+void gemm_split_weights_host(const float* w, int n, int k, int nplanes, uint16_t* out);
 
 // ---- row kernels (rowops.hip) ----------------------------------------------------------------
 hipError_t launch_frame_stack_lens(const float* raw, const int32_t* lens, int n, int raw_frames, int raw_dim, int left,

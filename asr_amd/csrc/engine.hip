@@ -166,10 +166,10 @@ struct ProfScope {
 const char* gemm_class_name(int nprod, int M, int N, int epilogue, int split_k)
 {
     static std::map<std::string, std::string> interned;           // stable c_str() for ProfClass::name
-    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    const int tile = nprod == 0 ? gemm_f32_pick_tile(M, N, split_k, epilogue) : tiles128 >= 512 ? 1 : 2;
+    const int tile = nprod == 0 ? gemm_f32_pick_tile(M, N, split_k, epilogue) : gemm_split_pick_tile(M, N, split_k, epilogue);
     std::string n = nprod == 0 ? "gemm_f32_nt" : nprod == 6 ? "gemm_bf16x6_nt" : nprod == 3 ? "gemm_bf16x3_nt" : "gemm_bf16_nt";
-    n += tile == 1 ? "<128,128," : tile == 4 ? "<128,64," : "<64,64,";
+    if (nprod) n += tile == 1 ? "<128,128," : tile == 5 ? "<160,128," : tile == 6 ? "<96,128," : "<64,128,";
+    else n += tile == 1 ? "<128,128," : tile == 4 ? "<128,64," : "<64,64,";
     n += epilogue == EPI_GLU ? "GLU>" : epilogue == EPI_PARTIAL ? "PARTIAL>" : epilogue == EPI_BIAS ? "BIAS>" : "ACT>";
     auto it = interned.find(n);
     if (it == interned.end()) it = interned.emplace(n, n).first;
@@ -296,8 +296,9 @@ int upload(asr_handle* h, const std::string& name, float** dst)
 }
 
 // a GEMM operand: f32 [N][K] as is, or split into bf16 planes [planes][N][K] (gemm_split.hip)
-int upload_gemm_host(asr_handle* h, const float* w, size_t count, float** dst)
+int upload_gemm_host(asr_handle* h, const float* w, int n, int k, float** dst)
 {
+    const size_t count = (size_t)n * k;
     if (h->nprod == 0) {
         int rc = dev_alloc_t(h, dst, count);
         if (rc) return rc;
@@ -305,8 +306,8 @@ int upload_gemm_host(asr_handle* h, const float* w, size_t count, float** dst)
         return ASR_OK;
     }
     const int npl = gemm_split_planes(h->nprod);
-    std::vector<uint16_t> planes((size_t)npl * count);
-    gemm_split_weights_host(w, count, npl, planes.data());
+    std::vector<uint16_t> planes(gemm_split_weight_elems(n, k, npl));
+    gemm_split_weights_host(w, n, k, npl, planes.data());
     uint16_t* d = nullptr;
     int rc = dev_alloc_t(h, &d, planes.size());
     if (rc) return rc;
@@ -318,7 +319,8 @@ int upload_gemm_host(asr_handle* h, const float* w, size_t count, float** dst)
 int upload_gemm(asr_handle* h, const std::string& name, float** dst)
 {
     const HostTensor& t = h->staged.at(name);
-    return upload_gemm_host(h, t.data.data(), t.data.size(), dst);
+    if (t.shape.size() != 2) return fail(h, ASR_ERR_ARG, "GEMM operand is not a matrix");
+    return upload_gemm_host(h, t.data.data(), (int)t.shape[0], (int)t.shape[1], dst);
 }
 
 // ff_hidden first dense: GLU weights packed [2F][H] per 32 rows: 16 value rows | 16 gate rows
@@ -342,7 +344,7 @@ int upload_ffn1(asr_handle* h, const std::string& p, float** w, float** b)
             bp[(size_t)g * 32 + r] = b1.data[(size_t)g * 16 + r];
             bp[(size_t)g * 32 + 16 + r] = b2.data[(size_t)g * 16 + r];
         }
-    int rc = upload_gemm_host(h, wp.data(), wp.size(), w);
+    int rc = upload_gemm_host(h, wp.data(), 2 * F, H, w);
     if (rc) return rc;
     rc = dev_alloc_t(h, b, bp.size());
     if (rc) return rc;
@@ -818,12 +820,12 @@ struct TmpBufs {
         return e;
     }
     // a GEMM weight operand in the handle's precision mode (f32, or bf16 planes)
-    int up_gemm(asr_handle* h, float** d, const float* w, size_t count, hipStream_t s)
+    int up_gemm(asr_handle* h, float** d, const float* w, int n, int k, hipStream_t s)
     {
-        if (h->nprod == 0) { HIP_TRY(h, up(d, w, count, s)); return ASR_OK; }
+        if (h->nprod == 0) { HIP_TRY(h, up(d, w, (size_t)n * k, s)); return ASR_OK; }
         const int npl = gemm_split_planes(h->nprod);
-        std::vector<uint16_t> planes((size_t)npl * count);
-        gemm_split_weights_host(w, count, npl, planes.data());
+        std::vector<uint16_t> planes(gemm_split_weight_elems(n, k, npl));
+        gemm_split_weights_host(w, n, k, npl, planes.data());
         uint16_t* dp = nullptr;
         HIP_TRY(h, up(&dp, planes.data(), planes.size(), s));
         HIP_TRY(h, hipStreamSynchronize(s));                   // `planes` is a local
@@ -1251,7 +1253,7 @@ int asr_op_dense(asr_handle* h, const float* x, const float* w, const float* bia
     float *dx, *dw, *db = nullptr, *dy, *dpart = nullptr;
     hipStream_t s = h->stream;
     HIP_TRY(h, tb.up(&dx, x, (size_t)m * k, s));
-    if ((rc = tb.up_gemm(h, &dw, w, (size_t)n * k, s))) return rc;
+    if ((rc = tb.up_gemm(h, &dw, w, n, k, s))) return rc;
     if (bias) HIP_TRY(h, tb.up(&db, bias, (size_t)n, s));
     HIP_TRY(h, tb.up<float>(&dy, nullptr, (size_t)m * n, s));
     if (split_k == 1) {
@@ -1296,7 +1298,7 @@ int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float
     float *dx, *dw, *db, *dy;
     hipStream_t s = h->stream;
     HIP_TRY(h, tb.up(&dx, x, (size_t)m * k, s));
-    if ((rc = tb.up_gemm(h, &dw, wp.data(), wp.size(), s))) return rc;
+    if ((rc = tb.up_gemm(h, &dw, wp.data(), 2 * n, k, s))) return rc;
     HIP_TRY(h, tb.up(&db, bp.data(), bp.size(), s));
     HIP_TRY(h, tb.up<float>(&dy, nullptr, (size_t)m * n, s));
     if ((rc = gemm(h, dx, dw, db, dy, m, 2 * n, k, EPI_GLU, 1))) return rc;

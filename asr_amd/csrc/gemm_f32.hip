@@ -306,6 +306,7 @@ void gemm_force_reg_stage(bool on) { g_force_reg_stage = on; }
 
 int gemm_pick_split_k(int M, int N, int K, int nprod)
 {
+    if (nprod) return gemm_split_pick_split_k(M, N, K, nprod);
     // Decode-time projections (M = batch*beam rows) run 64x64 tiles, 4 waves each.  The f32 MFMA pipe is
     // the bound, so what matters is how evenly the waves fill the 1024 SIMDs: w waves per SIMD cost
     // ceil(w) turns of (K / split) / 32 k-tiles (0.45 us each); every extra slab costs one more write +

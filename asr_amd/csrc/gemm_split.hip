@@ -7,14 +7,25 @@
 // and six v_mfma_f32_32x32x16_bf16 (f32 accumulate) per 16-deep k-step replace eight
 // v_mfma_f32_32x32x2_f32: 192 instead of 512 matrix-pipe cycles at the accuracy of an f32 FMA chain
 // (tests/test_gpu_kernels.py compares both against float64).  NPROD selects how many of the products
-// are kept: 6 = "f32 via bf16x6" (default product path), 3 = hh+hm+mh (~2^-16), 1 = plain bf16.
+// are kept: 6 = "f32 via bf16x6", 3 = hh+hm+mh (~2^-16), 1 = plain bf16.
 //
 // Replaces utils.dense (transformer/utils.py:546-557) and the GLU pairing of utils.py:559-561.
-// Weights are split once at load time into bf16 planes [NPL][N][K]; activations are split while they
-// are staged into LDS.  LDS image per plane: [rows][4 chunks of 16 B] (BK = 32 bf16), chunk XOR-swizzled
-// by (row >> 2) & 3 so that both the 16-byte stores and the fragment reads are conflict-free.
+//
+// Shape of the kernel: a workgroup is 4 waves side by side along N; wave w owns columns [32 NI w, 32 NI (w+1)) of
+// the BM x BN tile (BM = 32 MI up to 160, BN = 128 NI) for ALL BM rows.  So
+//   * W fragments are private to a wave and never touch LDS.  Weights are split ONCE at load time
+//     (gemm_split_weights_host) and stored in MFMA fragment order: [N/32 row panels][K/32 k-tiles][plane][k-step]
+//     [lane] x 16 bytes, lane (l31, half) holding row l31, k = 16 kstep + 8 half .. + 8.  A wave's load of one
+//     fragment is one contiguous 1 KB run and its registers ARE the MFMA operand;
+//   * A (activations, f32 [M][K], small and L2-resident) is shared by the 4 waves: staged through LDS, split into
+//     planes on the way in (LDS image per plane [rows][4 chunks of 16 B], chunk XOR (row >> 2) & 3: stores and
+//     fragment reads conflict-free), double-buffered with ONE barrier per k-tile;
+//   * two register sets keep the global loads of the next two k-tiles in flight, and the side work of a k-tile is
+//     dealt out between its MFMAs by hand (see "the k-tile" below).
+// M = 640 beam rows x N = 8192 (the GLU layer) is 4 x 64 tiles of 160 x 128: one workgroup per CU.
 #include "asr_common.h"
 #include "gemm_epilogue.h"
+#include <math.h>
 #include <string.h>
 #include <type_traits>
 
@@ -27,39 +38,22 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// 8 floats -> NPL bf16 planes of 8 values each (packed 2 per dword, element 0 in the low half)
-template <int NPL>
-__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, u32x4 (&out)[NPL])
-{
-#pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {
-        f32x2 v = pr < 2 ? f32x2{x0[2 * pr], x0[2 * pr + 1]} : f32x2{x1[2 * pr - 4], x1[2 * pr - 3]};
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            const bf16x2 b = __builtin_convertvector(v, bf16x2);
-            out[pl][pr] = __builtin_bit_cast(uint32_t, b);
-            if (pl + 1 < NPL) v = v - __builtin_convertvector(b, f32x2);      // exact
-        }
-    }
-}
-
-template <int BM, int BN, int WM, int WN, int EPI, int NPROD>
+template <int MI, int NI, int EPI, int NPROD>
 __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
 {
     constexpr int NPL = NPROD == 6 ? 3 : NPROD == 3 ? 2 : 1;
-    constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    static_assert(BM % 64 == 0 && BN % 64 == 0, "staging covers 64 rows per pass");
-    constexpr int A_LD = BM / 64, B_LD = BN / 64;
+    constexpr int WN = NI * 32, BM = MI * 32, BN = 4 * WN;
+    constexpr int A_LD = (BM + 63) / 64;               // staging passes of 64 rows
+    constexpr int AR = A_LD * 64;                      // LDS rows (tile padded to whole passes: every staging load and
+                                                       // store is unconditional, so the compiler's wait counts are exact)
+    constexpr int STAGE = NPL * AR * 4;                // u32x4 per LDS stage
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    u32x4* As = reinterpret_cast<u32x4*>(smem_raw);    // [NPL][BM][4]
-    u32x4* Bs = As + NPL * BM * 4;                     // [NPL][BN][4]
+    u32x4* lds = reinterpret_cast<u32x4*>(smem_raw);   // [2][NPL][AR][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // XCD-aware tile order (same as gemm_f32.hip)
+    // XCD-aware tile order (same as gemm_f32.hip): each XCD gets a contiguous run of tiles, M-tile fastest
     const int total = nt_m * nt_n;
     const int bid = blockIdx.x;
     const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
@@ -76,8 +70,10 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
     const int kbeg = z * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
     const int nk = (kend - kbeg) / SBK;                // K % 32 == 0 (checked by the launcher)
+    const int kt0 = kbeg / SBK;                        // first k-tile of this slice
+    const int nkt = p.K / SBK;                         // k-tiles per panel
 
-    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int wn0 = wave * WN;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -87,103 +83,221 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.0f;
 
-    // staging: thread -> row (tid >> 2) + 64 i, k-chunk (tid & 3) of 8; rows past M / N are clamped (their
-    // products land in C rows / columns that are never stored), so every load is unconditional
+    // A staging: thread -> row (tid >> 2) + 64 i, 8 floats at k = 8 (tid & 3).  Rows past M are clamped (their products
+    // land in C rows that are never stored).
     const int srow = tid >> 2, sch = tid & 3;
     const float* arow[A_LD];
-    const uint16_t* brow[B_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) arow[i] = p.A + (size_t)min(m0 + srow + 64 * i, p.M - 1) * p.lda + sch * 8;
+    // W fragments: panel (n0 + wn0) / 32 + n of this wave (clamped past the last panel: columns never stored)
+    const int npanels = (p.N + 31) >> 5;
+    const u32x4* wfrag[NI];
 #pragma unroll
-    for (int i = 0; i < B_LD; ++i) brow[i] = p.Wp + (size_t)min(n0 + srow + 64 * i, p.N - 1) * p.K + sch * 8;
-    const size_t wplane = (size_t)p.N * p.K;
+    for (int n = 0; n < NI; ++n)
+        wfrag[n] = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)min(((n0 + wn0) >> 5) + n, npanels - 1) * nkt * (NPL * 128) + lane;
 
-    f32x4 ra[A_LD][2];
-    u32x4 rb[B_LD][NPL];
-    auto gload = [&](int k0) {
+    // register sets (set = k-tile parity): A as loaded, W as the MFMA consumes it
+    f32x4 ra[2][A_LD][2];
+    bf16x8 rw[2][2][NPL][NI];                          // [set][k-step][plane][n]
+    auto ktile_k0 = [&](int t) { return kbeg + (t < nk ? t : 0) * SBK; };                       // past the slice: a harmless re-read
+    auto ktile_woff = [&](int t) { return (size_t)(kt0 + (t < nk ? t : 0)) * (NPL * 128); };
+    auto gload_a = [&](auto setc, int t) {
+        constexpr int S = decltype(setc)::value;
+        const int k0 = ktile_k0(t);
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            ra[i][0] = *reinterpret_cast<const f32x4*>(arow[i] + k0);
-            ra[i][1] = *reinterpret_cast<const f32x4*>(arow[i] + k0 + 4);
+            ra[S][i][0] = *reinterpret_cast<const f32x4*>(arow[i] + k0);
+            ra[S][i][1] = *reinterpret_cast<const f32x4*>(arow[i] + k0 + 4);
         }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i)
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) rb[i][pl] = *reinterpret_cast<const u32x4*>(brow[i] + pl * wplane + k0);
     };
-    auto lstore = [&]() {
+    auto gload_w = [&](auto setc, int t, int ks) {
+        constexpr int S = decltype(setc)::value;
+        const size_t off = ktile_woff(t) + ks * 64;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const u32x4 v = wfrag[n][off + pl * 128];
+                if (ks == 0) rw[S][0][pl][n] = __builtin_bit_cast(bf16x8, v); else rw[S][1][pl][n] = __builtin_bit_cast(bf16x8, v);
+            }
+    };
+    u32x4 pieces[A_LD][NPL];
+    f32x2 rest[A_LD];                                  // what is left of the pair being split
+    // A staging, in small steps (so that they can be dealt out between MFMAs): per pass of 64 rows, for each of the 4
+    // pairs of floats: (pair, 0) = plane 0 and the remainder, (pair, 1) = the other planes; then one store group
+    constexpr int APASS = 4 * 2 + 1;
+    auto astage = [&](auto setc, int buf, int op) {
+        constexpr int S = decltype(setc)::value;
+        u32x4* As = lds + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            const int row = srow + 64 * i;
-            u32x4 pieces[NPL];
-            split8<NPL>(ra[i][0], ra[i][1], pieces);
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) As[(pl * BM + row) * 4 + (sch ^ ((row >> 2) & 3))] = pieces[pl];
-        }
+            for (int pr = 0; pr < 4; ++pr) {
+                if (op == i * APASS + 2 * pr) {
+                    const f32x4& x = ra[S][i][pr >> 1];
+                    f32x2 v = {x[2 * (pr & 1)], x[2 * (pr & 1) + 1]};
+                    const bf16x2 b = __builtin_convertvector(v, bf16x2);
+                    pieces[i][0][pr] = __builtin_bit_cast(uint32_t, b);
+                    if (NPL > 1) rest[i] = v - __builtin_convertvector(b, f32x2);          // exact
+                }
+                if (op == i * APASS + 2 * pr + 1) {
+                    f32x2 v = rest[i];
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int row = srow + 64 * i;
+                    for (int pl = 1; pl < NPL; ++pl) {
+                        const bf16x2 b = __builtin_convertvector(v, bf16x2);
+                        pieces[i][pl][pr] = __builtin_bit_cast(uint32_t, b);
+                        if (pl + 1 < NPL) v = v - __builtin_convertvector(b, f32x2);       // exact
+                    }
+                }
+            }
+            if (op == i * APASS + 8) {
+                const int row = srow + 64 * i;
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) Bs[(pl * BN + row) * 4 + (sch ^ ((row >> 2) & 3))] = rb[i][pl];
+                for (int pl = 0; pl < NPL; ++pl) As[(pl * AR + row) * 4 + (sch ^ ((row >> 2) & 3))] = pieces[i][pl];
+            }
         }
     };
 
     const int l31 = lane & 31, lhalf = lane >> 5;
-    if (nk > 0) gload(kbeg);
-    for (int kt = 0; kt < nk; ++kt) {
-        lstore();
-        __syncthreads();
-        gload(kt + 1 < nk ? kbeg + (kt + 1) * SBK : kbeg);        // next tile (or a harmless re-read) flies under the MFMAs
+    bf16x8 af[2][NPL][MI];                             // A fragments of the current / next k-step
+    auto fload_one = [&](auto slotc, int buf, int ks, int op) {          // op = i * NPL + pl
+        constexpr int S = decltype(slotc)::value;
+        const u32x4* As = lds + buf * STAGE;
+        const int ch = 2 * ks + lhalf;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = 2 * ks + lhalf;
-            bf16x8 af[NPL][MI], bf[NPL][NI];
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int row = wm0 + i * 32 + l31;
-                    af[pl][i] = __builtin_bit_cast(bf16x8, As[(pl * BM + row) * 4 + (ch ^ ((row >> 2) & 3))]);
+            for (int pl = 0; pl < NPL; ++pl)
+                if (op == i * NPL + pl) {
+                    const int row = i * 32 + l31;
+                    af[S][pl][i] = __builtin_bit_cast(bf16x8, As[(pl * AR + row) * 4 + (ch ^ ((row >> 2) & 3))]);
                 }
+    };
+
+    // ---- the k-tile, scheduled by hand ------------------------------------------------------------------
+    // Left to itself the compiler sinks every fragment read to just before the MFMA that uses it (it minimises live
+    // ranges), which exposes one LDS latency per MFMA group: 3800 instead of 1920 cycles per k-tile at 160 x 128.
+    // So the side work of a k-tile is dealt out evenly between its MFMAs and pinned with sched_barrier:
+    //   step 0 (MFMAs of k-step 0): A fragment reads of k-step 1; A of tile kt+1 from registers into the other LDS
+    //           buffer, split a pair of floats at a time; W loads (tile kt+1, k-step 1); barrier;
+    //   step 1 (MFMAs of k-step 1): first A fragment reads of tile kt+1; global A loads of tile kt+3 (into the set
+    //           just staged); W loads (tile kt+2, k-step 0) into the registers step 0 has just finished with.
+    constexpr int NM = MI * NI * NPROD;                  // MFMAs per 16-deep k-step
+    constexpr int NF = NPL * MI;                         // A fragment reads per k-step
+    constexpr int NA = A_LD * APASS;                     // A staging ops per k-tile
+    constexpr int NWL = NPL * NI;                        // W loads per k-step
+    constexpr int NAL = A_LD * 2;                        // A loads per k-tile
+    int g_k0 = 0;
+    size_t g_woff = 0;
+    auto side_gload_a = [&](auto setc, int op) {
+        constexpr int S = decltype(setc)::value;
 #pragma unroll
-                for (int n = 0; n < NI; ++n) {
-                    const int row = wn0 + n * 32 + l31;
-                    bf[pl][n] = __builtin_bit_cast(bf16x8, Bs[(pl * BN + row) * 4 + (ch ^ ((row >> 2) & 3))]);
+        for (int i = 0; i < A_LD; ++i)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                if (op == i * 2 + hh) ra[S][i][hh] = *reinterpret_cast<const f32x4*>(arow[i] + g_k0 + 4 * hh);
+    };
+    auto side_gload_w = [&](auto setc, auto ksc, int op) {             // op = pl * NI + n
+        constexpr int S = decltype(setc)::value;
+        constexpr int KS = decltype(ksc)::value;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int n = 0; n < NI; ++n)
+                if (op == pl * NI + n) rw[S][KS][pl][n] = __builtin_bit_cast(bf16x8, wfrag[n][g_woff + KS * 64 + pl * 128]);
+    };
+    // the MFMAs of k-step KS of the tile in W set WS, A fragments from slot FS; side ops [n NOPS / NM, (n + 1) NOPS / NM)
+    // follow the n-th MFMA
+    auto chunk = [&](auto fslotc, auto wsetc, auto ksc, auto nopsc, auto&& side) {
+        constexpr int FS = decltype(fslotc)::value;
+        constexpr int WS = decltype(wsetc)::value;
+        constexpr int KS = decltype(ksc)::value;
+        constexpr int NOPS = decltype(nopsc)::value;
+        auto one = [&](int idx, const bf16x8& a, const bf16x8& b, f32x16& c) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+            const int lo = idx * NOPS / NM, hi = (idx + 1) * NOPS / NM;
+#pragma unroll
+            for (int e = 0; e < (NOPS + NM - 1) / NM; ++e)
+                if (lo + e < hi) side(lo + e);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                const int base = (i * NI + n) * NPROD;
+                int q = 0;
+                // smallest products first; (a-plane, w-plane) pairs: 6 -> lh hl mm mh hm hh, 3 -> mh hm hh, 1 -> hh
+                if constexpr (NPROD == 6) {
+                    one(base + q++, af[FS][2][i], rw[WS][KS][0][n], acc[i][n]);
+                    one(base + q++, af[FS][0][i], rw[WS][KS][2][n], acc[i][n]);
+                    one(base + q++, af[FS][1][i], rw[WS][KS][1][n], acc[i][n]);
                 }
+                if constexpr (NPROD >= 3) {
+                    one(base + q++, af[FS][1][i], rw[WS][KS][0][n], acc[i][n]);
+                    one(base + q++, af[FS][0][i], rw[WS][KS][1][n], acc[i][n]);
+                }
+                one(base + q++, af[FS][0][i], rw[WS][KS][0][n], acc[i][n]);
             }
-            // smallest products first; (a-plane, w-plane) pairs: 6 -> lh hl mm mh hm hh, 3 -> mh hm hh, 1 -> hh
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int n = 0; n < NI; ++n) {
-                    if constexpr (NPROD == 6) {
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][n], acc[i][n], 0, 0, 0);
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][n], acc[i][n], 0, 0, 0);
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][n], acc[i][n], 0, 0, 0);
-                    }
-                    if constexpr (NPROD >= 3) {
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][n], acc[i][n], 0, 0, 0);
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][n], acc[i][n], 0, 0, 0);
-                    }
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][n], acc[i][n], 0, 0, 0);
-                }
-        }
+    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    // one k-tile kt whose parity is P: W set P holds tile kt, W set 1-P and A set 1-P hold tile kt+1
+    auto ktile = [&](auto parc, int kt) {
+        constexpr int P = decltype(parc)::value;
+        using cP = std::integral_constant<int, P>;
+        using cQ = std::integral_constant<int, 1 - P>;
+        const int buf = P;
+        g_woff = ktile_woff(kt + 1);
+        chunk(c0{}, cP{}, c0{}, std::integral_constant<int, NF + NA + NWL>{}, [&](int op) {
+            if (op < NF) fload_one(c1{}, buf, 1, op);
+            else if (op < NF + NA) astage(cQ{}, buf ^ 1, op - NF);
+            else side_gload_w(cQ{}, c1{}, op - NF - NA);
+        });
         __syncthreads();
+        g_k0 = ktile_k0(kt + 3);
+        g_woff = ktile_woff(kt + 2);
+        chunk(c1{}, cP{}, c1{}, std::integral_constant<int, NF + NAL + NWL>{}, [&](int op) {
+            if (op < NF) fload_one(c0{}, buf ^ 1, 0, op);
+            else if (op < NF + NAL) side_gload_a(cQ{}, op - NF);
+            else side_gload_w(cP{}, c0{}, op - NF - NAL);
+        });
+    };
+    if (nk > 0) {
+        gload_a(c0{}, 0);
+        gload_w(c0{}, 0, 0);
+        gload_w(c0{}, 0, 1);
+        gload_a(c1{}, 1);
+        gload_w(c1{}, 1, 0);
+#pragma unroll
+        for (int op = 0; op < NA; ++op) astage(c0{}, 0, op);
+        gload_a(c0{}, 2);
+        __syncthreads();
+#pragma unroll
+        for (int op = 0; op < NF; ++op) fload_one(c0{}, 0, 0, op);
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            ktile(c0{}, kt);
+            ktile(c1{}, kt + 1);
+        }
+        if (kt < nk) ktile(c0{}, kt);                     // odd tile count
     }
 
-    gemm_store_tile<EPI, MI, NI>(p, acc, m0, n0, wm0, wn0, z, lane);
+    gemm_store_tile<EPI, MI, NI>(p, acc, m0, n0, 0, wn0, z, lane);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NPROD>
+template <int MI, int NI, int EPI, int NPROD>
 hipError_t launch_split_tile(const GemmArgs& a, hipStream_t s)
 {
     constexpr int NPL = NPROD == 6 ? 3 : NPROD == 3 ? 2 : 1;
+    constexpr int BM = MI * 32, BN = 4 * NI * 32;
+    constexpr int AR = (BM + 63) / 64 * 64;
     const int nt_m = (a.M + BM - 1) / BM, nt_n = (a.N + BN - 1) / BN;
     const int split = a.split_k < 1 ? 1 : a.split_k;
     int kchunk = (a.K + split - 1) / split;
     kchunk = (kchunk + SBK - 1) / SBK * SBK;
-    const size_t lds = (size_t)NPL * (BM + BN) * 4 * sizeof(u32x4);
-    auto kern = gemm_split_nt_kernel<BM, BN, WM, WN, EPI, NPROD>;
+    const size_t lds = (size_t)2 * NPL * AR * 4 * sizeof(u32x4);
+    auto kern = gemm_split_nt_kernel<MI, NI, EPI, NPROD>;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -200,10 +314,10 @@ template <int EPI, int NPROD>
 hipError_t launch_split_epi(const GemmArgs& a, int tile, hipStream_t s)
 {
     switch (tile) {
-        case 1: return launch_split_tile<128, 128, 64, 64, EPI, NPROD>(a, s);
-        case 3: return launch_split_tile<64, 128, 32, 64, EPI, NPROD>(a, s);
-        case 4: return launch_split_tile<128, 64, 64, 32, EPI, NPROD>(a, s);
-        default: return launch_split_tile<64, 64, 32, 32, EPI, NPROD>(a, s);
+        case 1: return launch_split_tile<4, 1, EPI, NPROD>(a, s);     // 128 x 128
+        case 5: return launch_split_tile<5, 1, EPI, NPROD>(a, s);     // 160 x 128
+        case 6: return launch_split_tile<3, 1, EPI, NPROD>(a, s);     // 96 x 128
+        default: return launch_split_tile<2, 1, EPI, NPROD>(a, s);    // 64 x 128
     }
 }
 
@@ -244,16 +358,57 @@ static inline uint16_t f32_to_bf16_rne(float x, float* back)
     return (uint16_t)(r >> 16);
 }
 
-void gemm_split_weights_host(const float* w, size_t count, int nplanes, uint16_t* planes)
+size_t gemm_split_weight_elems(int n, int k, int nplanes) { return (size_t)((n + 31) / 32) * 32 * (size_t)k * nplanes; }
+
+// [n][k] f32 -> [n/32 panels][k/32 k-tiles][plane][k-step (2)][lane (64)] x 8 bf16: lane (l31, half) of k-step s holds
+// row 32 panel + l31, k = 32 kt + 16 s + 8 half .. + 8 (the B operand of v_mfma_f32_32x32x16_bf16); rows past n are zero
+void gemm_split_weights_host(const float* w, int n, int k, int nplanes, uint16_t* out)
 {
-    for (size_t i = 0; i < count; ++i) {
-        float v = w[i];
-        for (int pl = 0; pl < nplanes; ++pl) {
-            float back;
-            planes[(size_t)pl * count + i] = f32_to_bf16_rne(v, &back);
-            v = v - back;
+    const int nkt = k / 32;
+    memset(out, 0, gemm_split_weight_elems(n, k, nplanes) * sizeof(uint16_t));
+    for (int r = 0; r < n; ++r) {
+        const int panel = r >> 5, l31 = r & 31;
+        for (int c = 0; c < k; ++c) {
+            const int kt = c >> 5, ks = (c >> 4) & 1, half = (c >> 3) & 1, e = c & 7;
+            float v = w[(size_t)r * k + c];
+            uint16_t* blk = out + ((size_t)panel * nkt + kt) * nplanes * 1024 + (size_t)(ks * 64 + half * 32 + l31) * 8 + e;
+            for (int pl = 0; pl < nplanes; ++pl) {
+                float back;
+                blk[(size_t)pl * 1024] = f32_to_bf16_rne(v, &back);
+                v = v - back;
+            }
         }
     }
+}
+
+// 1 = 128x128, 2 = 64x128, 5 = 160x128, 6 = 96x128 (M x N).  Measured with tools/gemm_split_bench.hip on MI355X: the
+// 64 x 128 tile wins at every shape of the model, the 640 decode rows as well as the 21376 encoder rows (several
+// workgroups per CU hide each other's barrier and load latencies; under a dense MFMA load the chip lowers its clock,
+// so the taller tiles' better MFMA-per-byte ratio does not show as wall time).
+int gemm_split_pick_tile(int M, int N, int split_k, int epilogue)
+{
+    (void)M; (void)N; (void)split_k; (void)epilogue;
+    return 2;
+}
+
+// K-slices for the decode-time projections (64 x 128 tiles): a k-tile costs a workgroup about 0.6 us while it waits on
+// its own loads and barrier, about 0.45 us of matrix pipe when workgroups queue on a CU; every slab costs one more write
+// + read of M x N floats by the consumer.  Constants fitted to tools/gemm_split_bench.hip.
+int gemm_split_pick_split_k(int M, int N, int K, int nprod)
+{
+    const double tiles = (double)((M + 63) / 64) * ((N + 127) / 128);
+    if (tiles >= 1024) return 1;
+    const double pipe_us = 0.45 * (nprod == 6 ? 1.0 : nprod == 3 ? 0.6 : 0.4), lat_us = 0.6;
+    int best = 1;
+    double best_t = 1e30;
+    for (int split = 1; split <= ASR_MAX_SPLITK; split *= 2) {
+        if (split > 1 && K / split < 128) break;
+        const double kt = ceil((double)K / split / 32.0);
+        const double rounds = ceil(tiles * split / 256.0 - 1e-9);
+        const double t = fmax(rounds * kt * pipe_us, kt * lat_us) + split * (double)M * N * 8.0 / 4.0e6;
+        if (t < best_t - 1e-9) { best_t = t; best = split; }
+    }
+    return best;
 }
 
 hipError_t launch_gemm_split(const GemmArgs& a, int nprod, int tile_hint, hipStream_t s)
@@ -263,11 +418,7 @@ hipError_t launch_gemm_split(const GemmArgs& a, int nprod, int tile_hint, hipStr
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Wp)) & 15) return hipErrorInvalidValue;
     if (a.split_k > 1 && a.epilogue != EPI_PARTIAL) return hipErrorInvalidValue;
     if (a.epilogue == EPI_GLU && (a.N & 31)) return hipErrorInvalidValue;
-    int tile = tile_hint;
-    if (tile == 0) {
-        const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-        tile = tiles128 >= 512 ? 1 : 2;
-    }
+    const int tile = tile_hint ? tile_hint : gemm_split_pick_tile(a.M, a.N, a.split_k, a.epilogue);
     switch (nprod) {
         case 6: return launch_split_nprod<6>(a, tile, s);
         case 3: return launch_split_nprod<3>(a, tile, s);
