@@ -163,6 +163,11 @@ struct ProfScope {
     }
 };
 
+// bf16-plane kernels need whole 32-deep k-tiles; a GEMM whose K is not a multiple of 32 (no layer of the reference
+// configs; the single-kernel probes allow it) runs on the exact-f32 kernel in every precision mode.  Uploads and
+// launches both decide by this function, so the operand format always matches the kernel.
+inline int gemm_nprod(const asr_handle* h, int K) { return (K & 31) ? 0 : h->nprod; }
+
 const char* gemm_class_name(int nprod, int M, int N, int epilogue, int split_k)
 {
     static std::map<std::string, std::string> interned;           // stable c_str() for ProfClass::name
@@ -188,10 +193,11 @@ int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float
     a.split_k = split_k;
     a.epilogue = epilogue;
     const double nout = (epilogue == EPI_GLU) ? N / 2.0 : (double)N * split_k;
-    const double wbytes = h->nprod ? 2.0 * gemm_split_planes(h->nprod) : 4.0;
-    ProfScope ps(h, gemm_class_name(h->nprod, M, N, epilogue, split_k), 2.0 * M * N * (double)K,
+    const int nprod = gemm_nprod(h, K);
+    const double wbytes = nprod ? 2.0 * gemm_split_planes(nprod) : 4.0;
+    ProfScope ps(h, gemm_class_name(nprod, M, N, epilogue, split_k), 2.0 * M * N * (double)K,
                  4.0 * ((double)M * K + (double)M * nout) + wbytes * (double)N * K);
-    if (h->nprod) HIP_TRY(h, launch_gemm_split(a, h->nprod, 0, stream));
+    if (nprod) HIP_TRY(h, launch_gemm_split(a, nprod, 0, stream));
     else HIP_TRY(h, launch_gemm_f32(a, 0, stream));
     return ASR_OK;
 }
@@ -299,7 +305,7 @@ int upload(asr_handle* h, const std::string& name, float** dst)
 int upload_gemm_host(asr_handle* h, const float* w, int n, int k, float** dst)
 {
     const size_t count = (size_t)n * k;
-    if (h->nprod == 0) {
+    if (gemm_nprod(h, k) == 0) {
         int rc = dev_alloc_t(h, dst, count);
         if (rc) return rc;
         HIP_TRY(h, hipMemcpy(*dst, w, count * sizeof(float), hipMemcpyHostToDevice));
@@ -390,9 +396,9 @@ int ensure_encoder_capacity(asr_handle* h, int n, int t)
 
 int decode_splits(const asr_handle* h, int R, int* s_qkv, int* s_proj, int* s_ffn2)
 {
-    *s_qkv = gemm_pick_split_k(R, 3 * h->H, h->H, h->nprod);
-    *s_proj = gemm_pick_split_k(R, h->H, h->H, h->nprod);
-    *s_ffn2 = gemm_pick_split_k(R, h->H, h->F, h->nprod);
+    *s_qkv = gemm_pick_split_k(R, 3 * h->H, h->H, gemm_nprod(h, h->H));
+    *s_proj = gemm_pick_split_k(R, h->H, h->H, gemm_nprod(h, h->H));
+    *s_ffn2 = gemm_pick_split_k(R, h->H, h->F, gemm_nprod(h, h->F));
     return 0;
 }
 
@@ -421,7 +427,7 @@ int ensure_decoder_capacity(asr_handle* h, int n)
     rc |= dev_alloc_t(h, &h->dctx, R * H);
     rc |= dev_alloc_t(h, &h->part, (size_t)ASR_MAX_SPLITK * R * 3 * H);
     rc |= dev_alloc_t(h, &h->dhid, R * (size_t)h->F);
-    h->logit_split = std::min(2, gemm_pick_split_k((int)R, h->V, (int)H, h->nprod));        // <= 2 slabs of logits
+    h->logit_split = std::min(2, gemm_pick_split_k((int)R, h->V, (int)H, gemm_nprod(h, (int)H)));        // <= 2 slabs of logits
     rc |= dev_alloc_t(h, &h->logits, 2 * R * (size_t)h->V);
     rc |= dev_alloc_t(h, &h->cand_scores, R * (size_t)h->K);
     rc |= dev_alloc_t(h, &h->cand_tokens, R * (size_t)h->K);
@@ -640,7 +646,7 @@ int step_tail(asr_handle* h, const DecView& v, const StepCtx& c)
     hipStream_t s = v.stream;
     const BeamState& st = v.beam;
     const float* wout = h->cfg.tie_embedding_and_softmax ? h->emb_gemm : h->softmax_w;
-    const int s_log = std::min(2, gemm_pick_split_k(R, h->V, H, h->nprod));                          // <= 2 slabs of logits
+    const int s_log = std::min(2, gemm_pick_split_k(R, h->V, H, gemm_nprod(h, H)));                          // <= 2 slabs of logits
     int rc = gemm(h, v.y0, wout, nullptr, v.logits, R, h->V, H, EPI_PARTIAL, s_log, s);             // model.py:341 (no bias)
     if (rc) return rc;
     {
@@ -822,7 +828,7 @@ struct TmpBufs {
     // a GEMM weight operand in the handle's precision mode (f32, or bf16 planes)
     int up_gemm(asr_handle* h, float** d, const float* w, int n, int k, hipStream_t s)
     {
-        if (h->nprod == 0) { HIP_TRY(h, up(d, w, (size_t)n * k, s)); return ASR_OK; }
+        if (gemm_nprod(h, k) == 0) { HIP_TRY(h, up(d, w, (size_t)n * k, s)); return ASR_OK; }
         const int npl = gemm_split_planes(h->nprod);
         std::vector<uint16_t> planes(gemm_split_weight_elems(n, k, npl));
         gemm_split_weights_host(w, n, k, npl, planes.data());
@@ -879,8 +885,6 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     if (cfg->max_target_length < 1 || cfg->max_target_length > 4000) return bad("max_target_length must be in 1..4000");
     if (cfg->ff_activation < ASR_FF_RELU || cfg->ff_activation > ASR_FF_SWISH) return bad("unknown ff_activation");
     if (cfg->precision < ASR_PRECISION_F32 || cfg->precision > ASR_PRECISION_BF16) return bad("unknown precision");
-    if (cfg->precision != ASR_PRECISION_F32 && (cfg->input_dim & 31))
-        return bad("the bf16-plane GEMM modes need input_dim % 32 == 0 (use precision = ASR_PRECISION_F32)");
     if (cfg->sub_batches < 0 || cfg->sub_batches > 2) return bad("sub_batches must be 0 (default), 1 or 2");
     for (int i = 0; i < 2; ++i)
         if (cfg->reserved[i]) return bad("reserved fields must be zero");
@@ -990,7 +994,7 @@ int asr_finalize_weights(asr_handle* h)
     if ((rc = upload(h, "decoder/dst_embedding/kernel", &h->emb))) return rc;          // f32: the embedding lookup
     if (!h->cfg.tie_embedding_and_softmax) {
         if ((rc = upload_gemm(h, "decoder/softmax/kernel", &h->softmax_w))) return rc;
-    } else if (h->nprod) {
+    } else if (gemm_nprod(h, h->H)) {
         if ((rc = upload_gemm(h, "decoder/dst_embedding/kernel", &h->emb_gemm))) return rc;
     } else {
         h->emb_gemm = h->emb;
@@ -1246,7 +1250,6 @@ int asr_op_dense(asr_handle* h, const float* x, const float* w, const float* bia
 {
     if (!h || !x || !w || !y || m < 1 || n < 1 || k < 4 || (k & 3) || split_k < 1 || split_k > ASR_MAX_SPLITK)
         return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
-    if (h->nprod && (k & 31)) return fail(h, ASR_ERR_ARG, "the bf16-plane GEMM modes need k % 32 == 0");
     int rc = set_device(h);
     if (rc) return rc;
     TmpBufs tb;
@@ -1283,7 +1286,6 @@ int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float
 {
     if (!h || !x || !w1 || !w2 || !y || m < 1 || n < 16 || (n & 15) || k < 4 || (k & 3))
         return h ? fail(h, ASR_ERR_ARG, "bad argument (n must be a multiple of 16)") : ASR_ERR_ARG;
-    if (h->nprod && (k & 31)) return fail(h, ASR_ERR_ARG, "the bf16-plane GEMM modes need k % 32 == 0");
     int rc = set_device(h);
     if (rc) return rc;
     std::vector<float> wp((size_t)2 * n * k), bp((size_t)2 * n, 0.f);

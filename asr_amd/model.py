@@ -19,6 +19,12 @@ from . import _lib
 from ._lib import lib
 from .utils import shard_bounds
 
+# Arithmetic of the dense layers when the YAML has no `test.precision` key and ASR_AMD_PRECISION is unset: float32
+# operands split exactly into three bf16 terms, six bf16 matrix products per k-step, f32 accumulation - the accuracy of
+# an f32 FMA chain (same test bars as the exact-f32 matrix instructions, hypotheses identical) on the 16x faster bf16
+# matrix cores.  `precision: f32` selects the exact-f32 matrix instructions (include/asr_amd.h asr_precision).
+DEFAULT_PRECISION = 'f32_bf16x6'
+
 
 class Engine(object):
     """One libasr_amd handle = one GPU's weights, K/V caches and workspaces."""
@@ -42,7 +48,7 @@ class Engine(object):
         c.lp_alpha = float(t.lp_alpha)
         c.device = int(device)
         # build extension (not a reference key): arithmetic of the dense layers, see include/asr_amd.h asr_precision
-        prec = (t.precision if t.precision is not None else os.environ.get('ASR_AMD_PRECISION')) or 'f32'
+        prec = (t.precision if t.precision is not None else os.environ.get('ASR_AMD_PRECISION')) or DEFAULT_PRECISION
         if prec not in _lib.PRECISIONS:
             raise ValueError('unknown test.precision %r (one of %s)' % (prec, sorted(_lib.PRECISIONS)))
         c.precision = _lib.PRECISIONS[prec]

@@ -32,14 +32,14 @@ PEAK_HBM_GBS = 8000.0            # same guide: HBM3E 8 TB/s
 # dense-layer arithmetic (include/asr_amd.h asr_precision): reported dtype and MFMA products per f32 multiply-add
 PRECISION_INFO = {
     'f32': ('f32', 1, PEAK_F32_MFMA_TFLOPS),
-    'f32_bf16x6': ('f32 (operands split exactly into 3 bf16 terms, 6 bf16 MFMA products per k-step, f32 accumulate)', 6,
+    'f32_bf16x6': ('f32 (every f32 operand split exactly into 3 bf16 terms, 6 bf16 MFMA products per k-step, f32 accumulate: f32-chain accuracy)', 6,
                    PEAK_BF16_MFMA_TFLOPS),
     'bf16x3': ('bf16x3 (2-term bf16 split, 3 MFMA products, f32 accumulate)', 3, PEAK_BF16_MFMA_TFLOPS),
     'bf16': ('bf16 (f32 accumulate; attention, layer norms and beam search in f32)', 1, PEAK_BF16_MFMA_TFLOPS),
 }
 
 
-def bench_config(beam=10, mtl=200, precision='f32'):
+def bench_config(beam=10, mtl=200, precision='f32_bf16x6'):
     from asr_amd.utils import AttrDict
     return AttrDict({
         'model': 'Transformer', 'dst_vocab_size': 3900, 'hidden_units': 1024, 'scale_embedding': True,
@@ -106,7 +106,7 @@ def main():
     ap.add_argument('--max-target-length', type=int, default=200)
     ap.add_argument('--cpu-sample-utts', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32'), choices=sorted(PRECISION_INFO))
+    ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_bf16x6'), choices=sorted(PRECISION_INFO))
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))

@@ -39,7 +39,8 @@ enum asr_ff_activation { ASR_FF_RELU = 0, ASR_FF_GLU = 1, ASR_FF_SIGMOID = 2, AS
  * accumulates in float32 and keeps activations, attention, layer norms and the beam search in float32.
  *   F32         exact-f32 matrix instructions (v_mfma_f32_32x32x2_f32): products and sums in f32.
  *   F32_BF16X6  float32 operands split exactly into three bf16 terms each, six bf16 matrix products per k-step
- *               (terms below 2^-24 of the product dropped): f32-chain accuracy at 2.7x the matrix rate.
+ *               (terms below 2^-24 of the product dropped): f32-chain accuracy at 2.7x the matrix rate.  A layer
+ *               whose input width is not a multiple of 32 runs on the F32 kernel in this and the next two modes.
  *   BF16X3      two terms each, three products (~2^-16 relative product error).
  *   BF16        operands rounded to bf16 (north_star's "bf16 MFMA" mode; tolerance stated in the tests). */
 enum asr_precision { ASR_PRECISION_F32 = 0, ASR_PRECISION_F32_BF16X6 = 1, ASR_PRECISION_BF16X3 = 2, ASR_PRECISION_BF16 = 3 };
@@ -59,7 +60,8 @@ typedef struct asr_config {
     int32_t max_target_length;           /* test.max_target_length                        */
     float   lp_alpha;                    /* test.lp_alpha                                 */
     int32_t device;                      /* HIP device ordinal this handle lives on       */
-    int32_t precision;                   /* enum asr_precision (build extension; YAML key test.precision, default f32) */
+    int32_t precision;                   /* enum asr_precision (build extension; YAML key test.precision; the Python host's default
+                                            is F32_BF16X6, a zeroed struct means F32) */
     int32_t sub_batches;                 /* 1 = beam-search the batch as one run of kernels, 2 = as two independent halves on
                                             two streams (same results: utterances are independent), 0 = env
                                             ASR_AMD_SUBBATCH or automatic (two halves from 320 beam rows);
