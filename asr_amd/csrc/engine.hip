@@ -173,7 +173,7 @@ const char* gemm_class_name(int nprod, int M, int N, int epilogue, int split_k)
     static std::map<std::string, std::string> interned;           // stable c_str() for ProfClass::name
     const int tile = nprod == 0 ? gemm_f32_pick_tile(M, N, split_k, epilogue) : gemm_split_pick_tile(M, N, split_k, epilogue);
     std::string n = nprod == 0 ? "gemm_f32_nt" : nprod == 6 ? "gemm_bf16x6_nt" : nprod == 3 ? "gemm_bf16x3_nt" : "gemm_bf16_nt";
-    if (nprod) n += tile == 1 ? "<128,128," : tile == 5 ? "<160,128," : tile == 6 ? "<96,128," : "<64,128,";
+    if (nprod) n += tile == 1 ? "<128,128," : tile == 5 ? "<160,128," : tile == 6 ? "<96,128," : tile == 7 ? "<64,256," : tile == 8 ? "<96,256," : "<64,128,";
     else n += tile == 1 ? "<128,128," : tile == 4 ? "<128,64," : "<64,64,";
     n += epilogue == EPI_GLU ? "GLU>" : epilogue == EPI_PARTIAL ? "PARTIAL>" : epilogue == EPI_BIAS ? "BIAS>" : "ACT>";
     auto it = interned.find(n);

@@ -317,6 +317,8 @@ hipError_t launch_split_epi(const GemmArgs& a, int tile, hipStream_t s)
         case 1: return launch_split_tile<4, 1, EPI, NPROD>(a, s);     // 128 x 128
         case 5: return launch_split_tile<5, 1, EPI, NPROD>(a, s);     // 160 x 128
         case 6: return launch_split_tile<3, 1, EPI, NPROD>(a, s);     // 96 x 128
+        case 7: return launch_split_tile<2, 2, EPI, NPROD>(a, s);     // 64 x 256
+        case 8: return launch_split_tile<3, 2, EPI, NPROD>(a, s);     // 96 x 256
         default: return launch_split_tile<2, 1, EPI, NPROD>(a, s);    // 64 x 128
     }
 }
@@ -381,14 +383,16 @@ void gemm_split_weights_host(const float* w, int n, int k, int nplanes, uint16_t
     }
 }
 
-// 1 = 128x128, 2 = 64x128, 5 = 160x128, 6 = 96x128 (M x N).  Measured with tools/gemm_split_bench.hip on MI355X: the
-// 64 x 128 tile wins at every shape of the model, the 640 decode rows as well as the 21376 encoder rows (several
-// workgroups per CU hide each other's barrier and load latencies; under a dense MFMA load the chip lowers its clock,
-// so the taller tiles' better MFMA-per-byte ratio does not show as wall time).
+// 1 = 128x128, 2 = 64x128, 5 = 160x128, 6 = 96x128, 7 = 64x256, 8 = 96x256 (M x N).  Measured with
+// tools/gemm_split_bench.hip on MI355X: 64-row tiles win at every shape of the model, the 640 decode rows as well as the
+// 21376 encoder rows (several workgroups per CU hide each other's barrier and load latencies; under a dense MFMA load the
+// chip lowers its clock, so the taller tiles' better MFMA-per-byte ratio does not show as wall time).  Encoder-sized
+// problems take 256 columns per workgroup (half the A-splitting work per MFMA: +5 %).
 int gemm_split_pick_tile(int M, int N, int split_k, int epilogue)
 {
-    (void)M; (void)N; (void)split_k; (void)epilogue;
-    return 2;
+    (void)split_k; (void)epilogue;
+    const long tiles = (long)((M + 63) / 64) * ((N + 255) / 256);
+    return tiles >= 2048 ? 7 : 2;
 }
 
 // K-slices for the decode-time projections (64 x 128 tiles): a k-tile costs a workgroup about 0.6 us while it waits on

@@ -47,7 +47,9 @@ def _dense(eng, x, w, b, split_k=1):
 
 @pytest.mark.parametrize('m,n,k,split', [(37, 50, 128, 1), (640, 3072, 1024, 1), (640, 1024, 1024, 4),
                                          (640, 1024, 4096, 8), (30, 3900, 1024, 1), (2000, 1024, 320, 1),
-                                         (129, 257, 64, 2), (2672, 1024, 1024, 1)])
+                                         (129, 257, 64, 2), (2672, 1024, 1024, 1),
+                                         # one k-tile; an odd k-tile count split unevenly (64 + 32); the 256-column tile
+                                         (1, 64, 32, 1), (65, 130, 96, 2), (4100, 8200, 64, 1)])
 def test_dense_modes(mode_eng, m, n, k, split):
     mode, eng = mode_eng
     rng = np.random.default_rng(m * 7 + n)
