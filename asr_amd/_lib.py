@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libasr_amd.so')
 
 ASR_OK = 0
 FF_ACTIVATIONS = {'relu': 0, 'glu': 1, 'sigmoid': 2, 'tanh': 3, 'swish': 4}
-PRECISIONS = {'f32': 0, 'f32_bf16x6': 1, 'bf16x3': 2, 'bf16': 3}
+PRECISIONS = {'f32': 0, 'f32_bf16x6': 1, 'bf16x3': 2, 'bf16': 3, 'f32_f16x3': 4}
 
 
 class AsrError(RuntimeError):
@@ -89,6 +89,7 @@ def _load():
         'asr_get_profile': (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), i64p,
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), i32p]),
         'asr_device_bytes': (i64, [vp]),
+        'asr_range_retries': (i64, [vp]),
         'asr_crc32c': (C.c_uint32, [vp, i64, C.c_uint32]),
     }
     for name, (res, args) in sig.items():

@@ -29,6 +29,7 @@ struct GemmArgs {
     int lda, ldw, ldc;
     int split_k;       // >= 1; > 1 only with EPI_PARTIAL
     int epilogue;
+    int32_t* range_flag; // gemm_split.hip, nprod 13 only: set to 1 when an activation does not fit fp16 (may be null)
 };
 // tile_hint: 0 = choose from the shape, 1 = 128x128, 2 = 64x64, 3 = 64x128(M x N), 4 = 128x64
 int gemm_f32_pick_tile(int M, int N, int split_k, int epilogue);
@@ -38,7 +39,8 @@ int gemm_pick_split_k(int M, int N, int K, int nprod);
 // true: always use the register-staged main loop (the DMA-staged loop needs K % 32 == 0 and is the default when it applies)
 void gemm_force_reg_stage(bool on);
 
-// f32 GEMM on the bf16 matrix cores by operand splitting (gemm_split.hip); nprod = 6 (f32 accuracy), 3 or 1 (bf16).
+// f32 GEMM on the 16-bit matrix cores by operand splitting (gemm_split.hip); nprod = 13 (f32 accuracy by three fp16
+// products; operands must fit fp16's range, see GemmArgs.range_flag), 6 (f32 accuracy by six bf16 products), 3 or 1 (bf16).
 // Needs K % 32 == 0 and a.Wp = the weight matrix as made by gemm_split_weights_host (gemm_split_planes(nprod) bf16 planes in
 // the kernel's panel order; gemm_split_weight_elems() uint16 elements).
 // tile_hint: 0 = choose from the shape, 1 = 128x128, 2 = 64x128, 5 = 160x128, 6 = 96x128, 7 = 64x256, 8 = 96x256 (M x N)
@@ -47,7 +49,7 @@ int gemm_split_pick_tile(int M, int N, int split_k, int epilogue);
 int gemm_split_pick_split_k(int M, int N, int K, int nprod);
 int gemm_split_planes(int nprod);
 size_t gemm_split_weight_elems(int n, int k, int nplanes);
-void gemm_split_weights_host(const float* w, int n, int k, int nplanes, uint16_t* out);
+bool gemm_split_weights_host(const float* w, int n, int k, int nprod, uint16_t* out);
 
 // ---- row kernels (rowops.hip) ----------------------------------------------------------------
 hipError_t launch_frame_stack_lens(const float* raw, const int32_t* lens, int n, int raw_frames, int raw_dim, int left,

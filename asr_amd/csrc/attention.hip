@@ -382,6 +382,35 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
     const int g = lane >> 4, c = lane & 15;
     const int hidden = a.heads * 64, t = a.t, K = a.k;
 
+    const float* kb = a.kc + ((size_t)u * a.heads + h) * t * 64;
+    const float* vb = a.v + ((size_t)u * a.heads + h) * t * 64;
+    const int32_t* padrow = a.pad2 + (size_t)u * t;
+    float m_run[NB], l_run[NB];
+    f32x4 o[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        m_run[nb] = -INFINITY; l_run[nb] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[nb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int nblk = (t + 15) >> 4;
+    f32x4 kf[4], vf[4];
+    int32_t padv[4];                                           // branch-free loads: clamped indices, masks applied at use
+    auto load_block = [&](int blk) {
+        const int key0 = blk * 16;
+        const float* kr = kb + (size_t)min(key0 + c, t - 1) * 64 + 4 * g;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) kf[db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + 4 * g + r;
+            vf[r] = *reinterpret_cast<const f32x4*>(vb + (size_t)min(key, t - 1) * 64 + 4 * c);
+            padv[r] = padrow[min(key, t - 1)];
+        }
+    };
+    if (wave < nblk) load_block(wave);                       // the first K/V block flies while q is assembled
+
     // q fragments: split-K slabs fetched two at a time (independent loads in flight), summed in slab order
     f32x4 qf[NB][4], qb[4];
 #pragma unroll
@@ -417,34 +446,6 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
         }
     }
 
-    const float* kb = a.kc + ((size_t)u * a.heads + h) * t * 64;
-    const float* vb = a.v + ((size_t)u * a.heads + h) * t * 64;
-    const int32_t* padrow = a.pad2 + (size_t)u * t;
-    float m_run[NB], l_run[NB];
-    f32x4 o[NB][4];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        m_run[nb] = -INFINITY; l_run[nb] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[nb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    const int nblk = (t + 15) >> 4;
-    f32x4 kf[4], vf[4];
-    int32_t padv[4];                                           // branch-free loads: clamped indices, masks applied at use
-    auto load_block = [&](int blk) {
-        const int key0 = blk * 16;
-        const float* kr = kb + (size_t)min(key0 + c, t - 1) * 64 + 4 * g;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) kf[db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = key0 + 4 * g + r;
-            vf[r] = *reinterpret_cast<const f32x4*>(vb + (size_t)min(key, t - 1) * 64 + 4 * c);
-            padv[r] = padrow[min(key, t - 1)];
-        }
-    };
-    if (wave < nblk) load_block(wave);
     for (int blk = wave; blk < nblk; blk += 4) {
         f32x4 kc4[4], vc4[4];
         float bc[4];

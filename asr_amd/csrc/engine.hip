@@ -45,7 +45,11 @@ struct asr_handle {
     int H = 0, heads = 0, L = 0, V = 0, D = 0, F = 0, K = 0;
     bool glu = false;
     int ff_epi = EPI_RELU;
-    int nprod = 0;                      // 0: exact f32 MFMA GEMMs; 6 / 3 / 1: bf16 planes (gemm_split.hip)
+    int nprod = 0;                      // 0: exact f32 MFMA GEMMs; 13: fp16x3, 6 / 3 / 1: bf16 planes (gemm_split.hip)
+    int nprod_active = 0;               // = nprod, except while a call is repeated on the bf16x6 kernels (13 -> 6)
+    int32_t* range_flag = nullptr;      // device: set by an fp16x3 GEMM that met an activation outside fp16's range
+    int64_t range_retries = 0;          // calls repeated on the bf16x6 kernels so far
+    bool weights_out_of_range = false;  // single-kernel probes: the caller's weight operand did not fit fp16
     int logit_split = 1;                // K slices of the logits GEMM (their slabs are summed by the top-k kernel)
     float* emb_gemm = nullptr;          // logits operand when tied: = emb (f32 mode) or its bf16 planes
     hipStream_t stream = nullptr;
@@ -166,13 +170,29 @@ struct ProfScope {
 // bf16-plane kernels need whole 32-deep k-tiles; a GEMM whose K is not a multiple of 32 (no layer of the reference
 // configs; the single-kernel probes allow it) runs on the exact-f32 kernel in every precision mode.  Uploads and
 // launches both decide by this function, so the operand format always matches the kernel.
-inline int gemm_nprod(const asr_handle* h, int K) { return (K & 31) ? 0 : h->nprod; }
+inline int gemm_nprod(const asr_handle* h, int K) { return (K & 31) ? 0 : h->nprod_active; }
+// In fp16x3 mode (nprod 13) every plane-format operand holds both formats, [fp16 planes | bf16x6 planes], so that a call
+// whose activations leave fp16's range can be repeated on the bf16x6 kernels without touching the weights again.
+inline bool dual_format(const asr_handle* h, int K) { return h->nprod == 13 && !(K & 31); }
+inline size_t plane_elems(const asr_handle* h, int n, int k)
+{
+    if (dual_format(h, k)) return gemm_split_weight_elems(n, k, 2) + gemm_split_weight_elems(n, k, 3);
+    return gemm_split_weight_elems(n, k, gemm_split_planes(h->nprod));
+}
+// packs `w` [n][k] into `out` (plane_elems() uint16 values); false: a weight does not fit fp16 (fp16x3 mode only)
+inline bool pack_planes(const asr_handle* h, const float* w, int n, int k, uint16_t* out)
+{
+    if (!dual_format(h, k)) return gemm_split_weights_host(w, n, k, h->nprod, out);
+    const bool ok = gemm_split_weights_host(w, n, k, 13, out);
+    gemm_split_weights_host(w, n, k, 6, out + gemm_split_weight_elems(n, k, 2));
+    return ok;
+}
 
 const char* gemm_class_name(int nprod, int M, int N, int epilogue, int split_k)
 {
     static std::map<std::string, std::string> interned;           // stable c_str() for ProfClass::name
     const int tile = nprod == 0 ? gemm_f32_pick_tile(M, N, split_k, epilogue) : gemm_split_pick_tile(M, N, split_k, epilogue);
-    std::string n = nprod == 0 ? "gemm_f32_nt" : nprod == 6 ? "gemm_bf16x6_nt" : nprod == 3 ? "gemm_bf16x3_nt" : "gemm_bf16_nt";
+    std::string n = nprod == 0 ? "gemm_f32_nt" : nprod == 13 ? "gemm_f16x3_nt" : nprod == 6 ? "gemm_bf16x6_nt" : nprod == 3 ? "gemm_bf16x3_nt" : "gemm_bf16_nt";
     if (nprod) n += tile == 1 ? "<128,128," : tile == 5 ? "<160,128," : tile == 6 ? "<96,128," : tile == 7 ? "<64,256," : tile == 8 ? "<96,256," : "<64,128,";
     else n += tile == 1 ? "<128,128," : tile == 4 ? "<128,64," : "<64,64,";
     n += epilogue == EPI_GLU ? "GLU>" : epilogue == EPI_PARTIAL ? "PARTIAL>" : epilogue == EPI_BIAS ? "BIAS>" : "ACT>";
@@ -194,6 +214,8 @@ int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float
     a.epilogue = epilogue;
     const double nout = (epilogue == EPI_GLU) ? N / 2.0 : (double)N * split_k;
     const int nprod = gemm_nprod(h, K);
+    if (nprod == 6 && dual_format(h, K)) a.Wp += gemm_split_weight_elems(N, K, 2);        // the bf16x6 copy (a repeated call)
+    a.range_flag = nprod == 13 ? h->range_flag : nullptr;
     const double wbytes = nprod ? 2.0 * gemm_split_planes(nprod) : 4.0;
     ProfScope ps(h, gemm_class_name(nprod, M, N, epilogue, split_k), 2.0 * M * N * (double)K,
                  4.0 * ((double)M * K + (double)M * nout) + wbytes * (double)N * K);
@@ -311,9 +333,8 @@ int upload_gemm_host(asr_handle* h, const float* w, int n, int k, float** dst)
         HIP_TRY(h, hipMemcpy(*dst, w, count * sizeof(float), hipMemcpyHostToDevice));
         return ASR_OK;
     }
-    const int npl = gemm_split_planes(h->nprod);
-    std::vector<uint16_t> planes(gemm_split_weight_elems(n, k, npl));
-    gemm_split_weights_host(w, n, k, npl, planes.data());
+    std::vector<uint16_t> planes(plane_elems(h, n, k));
+    if (!pack_planes(h, w, n, k, planes.data())) return fail(h, ASR_ERR_WEIGHTS, "a weight does not fit fp16 (precision f32_f16x3)");
     uint16_t* d = nullptr;
     int rc = dev_alloc_t(h, &d, planes.size());
     if (rc) return rc;
@@ -829,9 +850,8 @@ struct TmpBufs {
     int up_gemm(asr_handle* h, float** d, const float* w, int n, int k, hipStream_t s)
     {
         if (gemm_nprod(h, k) == 0) { HIP_TRY(h, up(d, w, (size_t)n * k, s)); return ASR_OK; }
-        const int npl = gemm_split_planes(h->nprod);
-        std::vector<uint16_t> planes(gemm_split_weight_elems(n, k, npl));
-        gemm_split_weights_host(w, n, k, npl, planes.data());
+        std::vector<uint16_t> planes(plane_elems(h, n, k));
+        if (!pack_planes(h, w, n, k, planes.data())) h->weights_out_of_range = true;     // checked by the caller's retry wrapper
         uint16_t* dp = nullptr;
         HIP_TRY(h, up(&dp, planes.data(), planes.size(), s));
         HIP_TRY(h, hipStreamSynchronize(s));                   // `planes` is a local
@@ -853,6 +873,25 @@ int fea_roundtrip(asr_handle* h, const float* in, size_t in_count, float* out, s
     HIP_TRY(h, hipMemcpyAsync(out, dout, out_count * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return ASR_OK;
+}
+
+// fp16x3 mode: run a call; if one of its GEMMs met an activation (or, for the single-kernel probes, a weight) outside
+// fp16's range, discard the result and repeat the whole call on the bf16x6 kernels (same accuracy, no range limit).
+template <typename F>
+int with_range_retry(asr_handle* h, F&& run)
+{
+    h->weights_out_of_range = false;
+    int rc = run();
+    if (rc != ASR_OK || h->nprod != 13 || h->nprod_active != 13) return rc;
+    int32_t flag = 0;
+    HIP_TRY(h, hipMemcpy(&flag, h->range_flag, sizeof(flag), hipMemcpyDeviceToHost));
+    if (!flag && !h->weights_out_of_range) return ASR_OK;
+    HIP_TRY(h, hipMemset(h->range_flag, 0, sizeof(flag)));
+    h->range_retries += 1;
+    h->nprod_active = 6;
+    rc = run();
+    h->nprod_active = 13;
+    return rc;
 }
 
 }  // namespace
@@ -884,7 +923,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
         return bad("dst_vocab_size must be in [max(4, beam_size), 38400]");
     if (cfg->max_target_length < 1 || cfg->max_target_length > 4000) return bad("max_target_length must be in 1..4000");
     if (cfg->ff_activation < ASR_FF_RELU || cfg->ff_activation > ASR_FF_SWISH) return bad("unknown ff_activation");
-    if (cfg->precision < ASR_PRECISION_F32 || cfg->precision > ASR_PRECISION_BF16) return bad("unknown precision");
+    if (cfg->precision < ASR_PRECISION_F32 || cfg->precision > ASR_PRECISION_F32_F16X3) return bad("unknown precision");
     if (cfg->sub_batches < 0 || cfg->sub_batches > 2) return bad("sub_batches must be 0 (default), 1 or 2");
     for (int i = 0; i < 2; ++i)
         if (cfg->reserved[i]) return bad("reserved fields must be zero");
@@ -898,7 +937,8 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     h->D = cfg->input_dim; h->F = 4 * cfg->hidden_units; h->K = cfg->beam_size;
     h->glu = cfg->ff_activation == ASR_FF_GLU;
     h->nprod = cfg->precision == ASR_PRECISION_F32_BF16X6 ? 6 : cfg->precision == ASR_PRECISION_BF16X3 ? 3
-             : cfg->precision == ASR_PRECISION_BF16 ? 1 : 0;
+             : cfg->precision == ASR_PRECISION_BF16 ? 1 : cfg->precision == ASR_PRECISION_F32_F16X3 ? 13 : 0;
+    h->nprod_active = h->nprod;
     switch (cfg->ff_activation) {
         case ASR_FF_SIGMOID: h->ff_epi = EPI_SIGMOID; break;
         case ASR_FF_TANH: h->ff_epi = EPI_TANH; break;
@@ -913,6 +953,8 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     hipError_t e;
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return hip_fail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->range_flag), 16)) != hipSuccess) return hip_fail(e, "hipMalloc");
+    if ((e = hipMemset(h->range_flag, 0, 16)) != hipSuccess) return hip_fail(e, "hipMemset");
     if ((e = hipEventCreate(&h->pe0)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->pe1)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
@@ -937,6 +979,7 @@ void asr_destroy(asr_handle* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     for (auto& kv : h->allocs) (void)hipFree(kv.first);
+    if (h->range_flag) (void)hipFree(h->range_flag);
     if (h->done_host) (void)hipHostFree(h->done_host);
     for (auto ev : h->step_events) if (ev) (void)hipEventDestroy(ev);
     if (h->pe0) (void)hipEventDestroy(h->pe0);
@@ -987,6 +1030,27 @@ int asr_finalize_weights(asr_handle* h)
     for (const VarSpec& v : required_vars(h))
         if (!h->staged.count(v.name)) { if (nmiss++ < 12) missing += "\n  " + v.name; }
     if (nmiss) return fail(h, ASR_ERR_WEIGHTS, std::to_string(nmiss) + " variable(s) missing:" + missing + (nmiss > 12 ? "\n  ..." : ""));
+    if (h->nprod == 13) {
+        // fp16x3 needs every GEMM weight inside fp16's range and no weight row below 2^-10 throughout (gemm_split.hip); a
+        // checkpoint that is not runs on the bf16x6 kernels instead (same accuracy).
+        bool fits = true;
+        for (const auto& kv : h->staged) {
+            const HostTensor& t = kv.second;
+            if (t.shape.size() != 2) continue;                          // GEMM operands are the matrices
+            const size_t rows = (size_t)t.shape[0], cols = (size_t)t.shape[1];
+            for (size_t r = 0; r < rows && fits; ++r) {
+                float rmax = 0.f;
+                bool finite = true;
+                for (size_t c = 0; c < cols; ++c) {
+                    const float a = fabsf(t.data[r * cols + c]);
+                    if (!(a < 65504.0f)) finite = false;
+                    rmax = fmaxf(rmax, a);
+                }
+                if (!finite || (rmax > 0.f && rmax < 0.0009765625f)) fits = false;
+            }
+        }
+        if (!fits) h->nprod = h->nprod_active = 6;
+    }
     if ((rc = upload_gemm(h, "encoder/src_change/kernel", &h->w_src))) return rc;
     if ((rc = upload(h, "encoder/src_change/bias", &h->b_src))) return rc;
     if ((rc = upload(h, "encoder/LayerNorm/gamma", &h->in_gamma))) return rc;
@@ -1045,7 +1109,7 @@ int asr_finalize_weights(asr_handle* h)
     return ASR_OK;
 }
 
-int asr_decode_dev(asr_handle* h, const float* X_dev, int32_t n, int32_t t, int32_t d, int32_t raw_frames, int32_t raw_dim,
+static int asr_decode_dev_once(asr_handle* h, const float* X_dev, int32_t n, int32_t t, int32_t d, int32_t raw_frames, int32_t raw_dim,
                    int32_t left, int32_t right, int32_t sub, int32_t* Y, int64_t y_capacity, int32_t* len_out)
 {
     if (!h || !len_out || (n > 0 && (!X_dev || !Y))) return h ? fail(h, ASR_ERR_ARG, "null argument") : ASR_ERR_ARG;
@@ -1068,7 +1132,14 @@ int asr_decode_dev(asr_handle* h, const float* X_dev, int32_t n, int32_t t, int3
     return decode_core(h, X, n, t, Y, y_capacity, len_out, nullptr);
 }
 
-int asr_decode_trace(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, int32_t* Y, int64_t y_capacity,
+int asr_decode_dev(asr_handle* h, const float* X_dev, int32_t n, int32_t t, int32_t d, int32_t raw_frames, int32_t raw_dim,
+                   int32_t left, int32_t right, int32_t sub, int32_t* Y, int64_t y_capacity, int32_t* len_out)
+{
+    if (!h) return ASR_ERR_ARG;
+    return with_range_retry(h, [&]() { return asr_decode_dev_once(h, X_dev, n, t, d, raw_frames, raw_dim, left, right, sub, Y, y_capacity, len_out); });
+}
+
+static int asr_decode_trace_once(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, int32_t* Y, int64_t y_capacity,
                      int32_t* len_out, int32_t trace_steps, float* logits, float* scores, int32_t* tokens, int32_t* parents)
 {
     if (!h || !len_out || (n > 0 && (!X || !Y))) return h ? fail(h, ASR_ERR_ARG, "null argument") : ASR_ERR_ARG;
@@ -1083,6 +1154,13 @@ int asr_decode_trace(asr_handle* h, const float* X, int32_t n, int32_t t, int32_
     return decode_core(h, h->xin, n, t, Y, y_capacity, len_out, trace_steps > 0 ? &tr : nullptr);
 }
 
+int asr_decode_trace(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, int32_t* Y, int64_t y_capacity,
+                     int32_t* len_out, int32_t trace_steps, float* logits, float* scores, int32_t* tokens, int32_t* parents)
+{
+    if (!h) return ASR_ERR_ARG;
+    return with_range_retry(h, [&]() { return asr_decode_trace_once(h, X, n, t, d, Y, y_capacity, len_out, trace_steps, logits, scores, tokens, parents); });
+}
+
 int asr_decode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, int32_t* Y, int64_t y_capacity, int32_t* len_out)
 {
     return asr_decode_trace(h, X, n, t, d, Y, y_capacity, len_out, 0, nullptr, nullptr, nullptr, nullptr);
@@ -1090,7 +1168,7 @@ int asr_decode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, i
 
 // Replaces Evaluator.loss (evaluate.py:49-50): sess.run(model.loss_sum) for one tower = encoder, teacher-forced
 // decoder_impl on shift_right(Y) (model.py:171,492-557) and test_loss (model.py:350-360).
-int asr_loss(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, const int32_t* Y, int32_t ty, double* loss_sum)
+static int asr_loss_once(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, const int32_t* Y, int32_t ty, double* loss_sum)
 {
     if (!h || !loss_sum || (n > 0 && (!X || !Y))) return h ? fail(h, ASR_ERR_ARG, "null argument") : ASR_ERR_ARG;
     *loss_sum = 0.0;
@@ -1148,6 +1226,12 @@ int asr_loss(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, con
     for (float v : rl) acc += (double)v;
     *loss_sum = acc;
     return ASR_OK;
+}
+
+int asr_loss(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, const int32_t* Y, int32_t ty, double* loss_sum)
+{
+    if (!h) return ASR_ERR_ARG;
+    return with_range_retry(h, [&]() { return asr_loss_once(h, X, n, t, d, Y, ty, loss_sum); });
 }
 
 int asr_stack_frames(asr_handle* h, const float* feats, int32_t n_frames, int32_t dim, int32_t left, int32_t right, int32_t sub,
@@ -1226,7 +1310,7 @@ int asr_fea_splice(asr_handle* h, const float* feats, int32_t n_frames, int32_t 
                          });
 }
 
-int asr_encode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, float* enc_out, int32_t* pad_out)
+static int asr_encode_once(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, float* enc_out, int32_t* pad_out)
 {
     if (!h || !X || !enc_out) return h ? fail(h, ASR_ERR_ARG, "null argument") : ASR_ERR_ARG;
     if (!h->finalized) return fail(h, ASR_ERR_STATE, "asr_finalize_weights has not succeeded on this handle");
@@ -1243,9 +1327,15 @@ int asr_encode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, f
     return ASR_OK;
 }
 
+int asr_encode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, float* enc_out, int32_t* pad_out)
+{
+    if (!h) return ASR_ERR_ARG;
+    return with_range_retry(h, [&]() { return asr_encode_once(h, X, n, t, d, enc_out, pad_out); });
+}
+
 // ---- single-kernel probes ----------------------------------------------------------------------
 
-int asr_op_dense(asr_handle* h, const float* x, const float* w, const float* bias, int32_t m, int32_t n, int32_t k, int32_t split_k,
+static int asr_op_dense_once(asr_handle* h, const float* x, const float* w, const float* bias, int32_t m, int32_t n, int32_t k, int32_t split_k,
                  float* y)
 {
     if (!h || !x || !w || !y || m < 1 || n < 1 || k < 4 || (k & 3) || split_k < 1 || split_k > ASR_MAX_SPLITK)
@@ -1281,7 +1371,14 @@ int asr_op_dense(asr_handle* h, const float* x, const float* w, const float* bia
     return ASR_OK;
 }
 
-int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int32_t m,
+int asr_op_dense(asr_handle* h, const float* x, const float* w, const float* bias, int32_t m, int32_t n, int32_t k, int32_t split_k,
+                 float* y)
+{
+    if (!h) return ASR_ERR_ARG;
+    return with_range_retry(h, [&]() { return asr_op_dense_once(h, x, w, bias, m, n, k, split_k, y); });
+}
+
+static int asr_op_dense_glu_once(asr_handle* h, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int32_t m,
                      int32_t n, int32_t k, float* y)
 {
     if (!h || !x || !w1 || !w2 || !y || m < 1 || n < 16 || (n & 15) || k < 4 || (k & 3))
@@ -1307,6 +1404,13 @@ int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float
     HIP_TRY(h, hipMemcpyAsync(y, dy, (size_t)m * n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return ASR_OK;
+}
+
+int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int32_t m,
+                     int32_t n, int32_t k, float* y)
+{
+    if (!h) return ASR_ERR_ARG;
+    return with_range_retry(h, [&]() { return asr_op_dense_glu_once(h, x, w1, b1, w2, b2, m, n, k, y); });
 }
 
 int asr_op_add_layer_norm(asr_handle* h, const float* x, const float* delta, const float* dbias, const float* scale, const float* bias,
@@ -1478,6 +1582,8 @@ int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, 
 }
 
 int64_t asr_device_bytes(const asr_handle* h) { return h ? h->dev_bytes : 0; }
+
+int64_t asr_range_retries(const asr_handle* h) { return h ? h->range_retries : 0; }
 
 // crc32c (Castagnoli), slicing-by-8 on the host: the tensor / block checksum of TF-V2 checkpoints
 uint32_t asr_crc32c(const void* data, int64_t n, uint32_t crc)

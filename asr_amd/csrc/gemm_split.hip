@@ -9,6 +9,17 @@
 // (tests/test_gpu_kernels.py compares both against float64).  NPROD selects how many of the products
 // are kept: 6 = "f32 via bf16x6", 3 = hh+hm+mh (~2^-16), 1 = plain bf16.
 //
+// NPROD = 13 is "f32 via fp16x3": a float is split as x = x1 + 2^-11 x2 with x1 = fp16(x), x2 = fp16(2^11 (x - x1))
+// (11 + 11 significand bits, the scale keeps x2 in fp16's normal range), and
+//     x.y = x1 y1 + 2^-11 (x1 y2 + x2 y1) + O(2^-22 |x.y|)
+// with the two groups in two f32 accumulators that are combined in the epilogue: THREE v_mfma_f32_32x32x16_f16 per k-step.
+// Measured against float64 its rms error is below the exact-f32 kernel's (the small terms do not round against the
+// large ones).  What it costs is range: an operand of magnitude >= 65504 does not fit x1, and below 2^-14 x1 and x2 sink
+// into fp16's subnormals (absolute error <= 2^-36 per element: nothing beside ordinary elements, but a relative loss for
+// a row that is that small throughout).  Weights are checked row by row when they are packed; activations are checked as
+// they are split (a thread's largest magnitude must lie in [2^-10, 65504) or be 0), and a kernel that meets one outside
+// sets GemmArgs.range_flag - the caller must then discard the result (the engine repeats the call on the bf16x6 kernels).
+//
 // Replaces utils.dense (transformer/utils.py:546-557) and the GLU pairing of utils.py:559-561.
 //
 // Shape of the kernel: a workgroup is 4 waves side by side along N; wave w owns columns [32 NI w, 32 NI (w+1)) of
@@ -35,13 +46,33 @@ constexpr int SBK = 32;   // k-depth of one LDS stage
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float F16_MAX = 65504.0f;
+constexpr float F16_TINY = 0.0009765625f;    // 2^-10
+constexpr float F16X3_SCALE = 2048.0f;       // 2^11
+
+template <int NPROD> struct SplitMode {
+    static constexpr bool F16 = NPROD == 13;
+    static constexpr int NPL = F16 ? 2 : NPROD == 6 ? 3 : NPROD == 3 ? 2 : 1;    // operand planes
+    static constexpr int NMMA = F16 ? 3 : NPROD;                                 // MFMAs per fragment pair per k-step
+};
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mma32(const u32x4& a, const u32x4& b, const f32x16& c)
+{
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 template <int MI, int NI, int EPI, int NPROD>
 __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
 {
-    constexpr int NPL = NPROD == 6 ? 3 : NPROD == 3 ? 2 : 1;
+    constexpr bool F16 = SplitMode<NPROD>::F16;
+    constexpr int NPL = SplitMode<NPROD>::NPL;
     constexpr int WN = NI * 32, BM = MI * 32, BN = 4 * WN;
     constexpr int A_LD = (BM + 63) / 64;               // staging passes of 64 rows
     constexpr int AR = A_LD * 64;                      // LDS rows (tile padded to whole passes: every staging load and
@@ -76,12 +107,17 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
     const int wn0 = wave * WN;
 
     f32x16 acc[MI][NI];
+    f32x16 acc2[F16 ? MI : 1][F16 ? NI : 1];           // fp16x3: the 2^-11 group (x1 y2 + x2 y1)
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int n = 0; n < NI; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][n][r] = 0.0f;
+                if constexpr (F16) acc2[i][n][r] = 0.0f;
+            }
+    float amax = 0.0f;                                  // fp16x3: largest |activation| this thread has split
 
     // A staging: thread -> row (tid >> 2) + 64 i, 8 floats at k = 8 (tid & 3).  Rows past M are clamped (their products
     // land in C rows that are never stored).
@@ -98,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
 
     // register sets (set = k-tile parity): A as loaded, W as the MFMA consumes it
     f32x4 ra[2][A_LD][2];
-    bf16x8 rw[2][2][NPL][NI];                          // [set][k-step][plane][n]
+    u32x4 rw[2][2][NPL][NI];                           // [set][k-step][plane][n]
     auto ktile_k0 = [&](int t) { return kbeg + (t < nk ? t : 0) * SBK; };                       // past the slice: a harmless re-read
     auto ktile_woff = [&](int t) { return (size_t)(kt0 + (t < nk ? t : 0)) * (NPL * 128); };
     auto gload_a = [&](auto setc, int t) {
@@ -118,7 +154,7 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
                 const u32x4 v = wfrag[n][off + pl * 128];
-                if (ks == 0) rw[S][0][pl][n] = __builtin_bit_cast(bf16x8, v); else rw[S][1][pl][n] = __builtin_bit_cast(bf16x8, v);
+                if (ks == 0) rw[S][0][pl][n] = v; else rw[S][1][pl][n] = v;
             }
     };
     u32x4 pieces[A_LD][NPL];
@@ -136,17 +172,28 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
                 if (op == i * APASS + 2 * pr) {
                     const f32x4& x = ra[S][i][pr >> 1];
                     f32x2 v = {x[2 * (pr & 1)], x[2 * (pr & 1) + 1]};
-                    const bf16x2 b = __builtin_convertvector(v, bf16x2);
-                    pieces[i][0][pr] = __builtin_bit_cast(uint32_t, b);
-                    if (NPL > 1) rest[i] = v - __builtin_convertvector(b, f32x2);          // exact
+                    if constexpr (F16) {
+                        amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+                        const f16x2 b = __builtin_convertvector(v, f16x2);
+                        pieces[i][0][pr] = __builtin_bit_cast(uint32_t, b);
+                        rest[i] = (v - __builtin_convertvector(b, f32x2)) * F16X3_SCALE;          // exact
+                    } else {
+                        const bf16x2 b = __builtin_convertvector(v, bf16x2);
+                        pieces[i][0][pr] = __builtin_bit_cast(uint32_t, b);
+                        if (NPL > 1) rest[i] = v - __builtin_convertvector(b, f32x2);              // exact
+                    }
                 }
                 if (op == i * APASS + 2 * pr + 1) {
                     f32x2 v = rest[i];
+                    if constexpr (F16) {
+                        pieces[i][1][pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+                    } else {
 #pragma unroll
-                    for (int pl = 1; pl < NPL; ++pl) {
-                        const bf16x2 b = __builtin_convertvector(v, bf16x2);
-                        pieces[i][pl][pr] = __builtin_bit_cast(uint32_t, b);
-                        if (pl + 1 < NPL) v = v - __builtin_convertvector(b, f32x2);       // exact
+                        for (int pl = 1; pl < NPL; ++pl) {
+                            const bf16x2 b = __builtin_convertvector(v, bf16x2);
+                            pieces[i][pl][pr] = __builtin_bit_cast(uint32_t, b);
+                            if (pl + 1 < NPL) v = v - __builtin_convertvector(b, f32x2);           // exact
+                        }
                     }
                 }
             }
@@ -159,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
     };
 
     const int l31 = lane & 31, lhalf = lane >> 5;
-    bf16x8 af[2][NPL][MI];                             // A fragments of the current / next k-step
+    u32x4 af[2][NPL][MI];                              // A fragments of the current / next k-step
     auto fload_one = [&](auto slotc, int buf, int ks, int op) {          // op = i * NPL + pl
         constexpr int S = decltype(slotc)::value;
         const u32x4* As = lds + buf * STAGE;
@@ -170,7 +217,7 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
             for (int pl = 0; pl < NPL; ++pl)
                 if (op == i * NPL + pl) {
                     const int row = i * 32 + l31;
-                    af[S][pl][i] = __builtin_bit_cast(bf16x8, As[(pl * AR + row) * 4 + (ch ^ ((row >> 2) & 3))]);
+                    af[S][pl][i] = As[(pl * AR + row) * 4 + (ch ^ ((row >> 2) & 3))];
                 }
     };
 
@@ -182,7 +229,8 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
     //           buffer, split a pair of floats at a time; W loads (tile kt+1, k-step 1); barrier;
     //   step 1 (MFMAs of k-step 1): first A fragment reads of tile kt+1; global A loads of tile kt+3 (into the set
     //           just staged); W loads (tile kt+2, k-step 0) into the registers step 0 has just finished with.
-    constexpr int NM = MI * NI * NPROD;                  // MFMAs per 16-deep k-step
+    constexpr int NMMA = SplitMode<NPROD>::NMMA;
+    constexpr int NM = MI * NI * NMMA;                   // MFMAs per 16-deep k-step
     constexpr int NF = NPL * MI;                         // A fragment reads per k-step
     constexpr int NA = A_LD * APASS;                     // A staging ops per k-tile
     constexpr int NWL = NPL * NI;                        // W loads per k-step
@@ -204,7 +252,7 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int n = 0; n < NI; ++n)
-                if (op == pl * NI + n) rw[S][KS][pl][n] = __builtin_bit_cast(bf16x8, wfrag[n][g_woff + KS * 64 + pl * 128]);
+                if (op == pl * NI + n) rw[S][KS][pl][n] = wfrag[n][g_woff + KS * 64 + pl * 128];
     };
     // the MFMAs of k-step KS of the tile in W set WS, A fragments from slot FS; side ops [n NOPS / NM, (n + 1) NOPS / NM)
     // follow the n-th MFMA
@@ -213,8 +261,8 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
         constexpr int WS = decltype(wsetc)::value;
         constexpr int KS = decltype(ksc)::value;
         constexpr int NOPS = decltype(nopsc)::value;
-        auto one = [&](int idx, const bf16x8& a, const bf16x8& b, f32x16& c) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        auto one = [&](int idx, const u32x4& a, const u32x4& b, f32x16& c) {
+            c = mma32<F16>(a, b, c);
             const int lo = idx * NOPS / NM, hi = (idx + 1) * NOPS / NM;
 #pragma unroll
             for (int e = 0; e < (NOPS + NM - 1) / NM; ++e)
@@ -225,19 +273,25 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
-                const int base = (i * NI + n) * NPROD;
+                const int base = (i * NI + n) * NMMA;
                 int q = 0;
-                // smallest products first; (a-plane, w-plane) pairs: 6 -> lh hl mm mh hm hh, 3 -> mh hm hh, 1 -> hh
-                if constexpr (NPROD == 6) {
-                    one(base + q++, af[FS][2][i], rw[WS][KS][0][n], acc[i][n]);
-                    one(base + q++, af[FS][0][i], rw[WS][KS][2][n], acc[i][n]);
-                    one(base + q++, af[FS][1][i], rw[WS][KS][1][n], acc[i][n]);
+                if constexpr (F16) {
+                    one(base + q++, af[FS][0][i], rw[WS][KS][1][n], acc2[i][n]);        // x1 y2
+                    one(base + q++, af[FS][1][i], rw[WS][KS][0][n], acc2[i][n]);        // x2 y1
+                    one(base + q++, af[FS][0][i], rw[WS][KS][0][n], acc[i][n]);         // x1 y1
+                } else {
+                    // smallest products first; (a-plane, w-plane) pairs: 6 -> lh hl mm mh hm hh, 3 -> mh hm hh, 1 -> hh
+                    if constexpr (NPROD == 6) {
+                        one(base + q++, af[FS][2][i], rw[WS][KS][0][n], acc[i][n]);
+                        one(base + q++, af[FS][0][i], rw[WS][KS][2][n], acc[i][n]);
+                        one(base + q++, af[FS][1][i], rw[WS][KS][1][n], acc[i][n]);
+                    }
+                    if constexpr (NPROD >= 3) {
+                        one(base + q++, af[FS][1][i], rw[WS][KS][0][n], acc[i][n]);
+                        one(base + q++, af[FS][0][i], rw[WS][KS][1][n], acc[i][n]);
+                    }
+                    one(base + q++, af[FS][0][i], rw[WS][KS][0][n], acc[i][n]);
                 }
-                if constexpr (NPROD >= 3) {
-                    one(base + q++, af[FS][1][i], rw[WS][KS][0][n], acc[i][n]);
-                    one(base + q++, af[FS][0][i], rw[WS][KS][1][n], acc[i][n]);
-                }
-                one(base + q++, af[FS][0][i], rw[WS][KS][0][n], acc[i][n]);
             }
     };
     using c0 = std::integral_constant<int, 0>;
@@ -283,13 +337,22 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
         if (kt < nk) ktile(c0{}, kt);                     // odd tile count
     }
 
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int n = 0; n < NI; ++n) acc[i][n] += acc2[i][n] * (1.0f / F16X3_SCALE);
+        // outside fp16's range, or a row piece so small (largest of >= 32 values below 2^-10) that x1 / x2 fall into fp16's
+        // subnormals and lose relative accuracy: the caller repeats the call on the bf16x6 kernels
+        if ((!(amax < F16_MAX) || (amax > 0.0f && amax < F16_TINY)) && p.range_flag) atomicOr(p.range_flag, 1);
+    }
     gemm_store_tile<EPI, MI, NI>(p, acc, m0, n0, 0, wn0, z, lane);
 }
 
 template <int MI, int NI, int EPI, int NPROD>
 hipError_t launch_split_tile(const GemmArgs& a, hipStream_t s)
 {
-    constexpr int NPL = NPROD == 6 ? 3 : NPROD == 3 ? 2 : 1;
+    constexpr int NPL = SplitMode<NPROD>::NPL;
     constexpr int BM = MI * 32, BN = 4 * NI * 32;
     constexpr int AR = (BM + 63) / 64 * 64;
     const int nt_m = (a.M + BM - 1) / BM, nt_n = (a.N + BN - 1) / BN;
@@ -340,7 +403,7 @@ hipError_t launch_split_nprod(const GemmArgs& a, int tile, hipStream_t s)
 
 }  // namespace
 
-int gemm_split_planes(int nprod) { return nprod == 6 ? 3 : nprod == 3 ? 2 : 1; }
+int gemm_split_planes(int nprod) { return nprod == 6 ? 3 : nprod == 3 || nprod == 13 ? 2 : 1; }
 
 // host-side split of a weight matrix into bf16 planes (round to nearest even, like v_cvt_pk_bf16_f32)
 static inline uint16_t f32_to_bf16_rne(float x, float* back)
@@ -362,18 +425,36 @@ static inline uint16_t f32_to_bf16_rne(float x, float* back)
 
 size_t gemm_split_weight_elems(int n, int k, int nplanes) { return (size_t)((n + 31) / 32) * 32 * (size_t)k * nplanes; }
 
-// [n][k] f32 -> [n/32 panels][k/32 k-tiles][plane][k-step (2)][lane (64)] x 8 bf16: lane (l31, half) of k-step s holds
-// row 32 panel + l31, k = 32 kt + 16 s + 8 half .. + 8 (the B operand of v_mfma_f32_32x32x16_bf16); rows past n are zero
-void gemm_split_weights_host(const float* w, int n, int k, int nplanes, uint16_t* out)
+// [n][k] f32 -> [n/32 panels][k/32 k-tiles][plane][k-step (2)][lane (64)] x 8 values of 16 bits: lane (l31, half) of
+// k-step s holds row 32 panel + l31, k = 32 kt + 16 s + 8 half .. + 8 (the B operand of v_mfma_f32_32x32x16_*); rows past n
+// are zero.  nprod 6 / 3 / 1: bf16 planes h, m, l; nprod 13: fp16 planes y1 = fp16(y), y2 = fp16(2^11 (y - y1)).
+// Returns false (nprod 13 only) when the matrix does not suit fp16x3: a weight with |w| >= 65504 or not finite, or a row
+// whose largest magnitude is below 2^-10 (and not 0).
+bool gemm_split_weights_host(const float* w, int n, int k, int nprod, uint16_t* out)
 {
+    const int nplanes = gemm_split_planes(nprod);
     const int nkt = k / 32;
+    bool ok = true;
     memset(out, 0, gemm_split_weight_elems(n, k, nplanes) * sizeof(uint16_t));
     for (int r = 0; r < n; ++r) {
         const int panel = r >> 5, l31 = r & 31;
+        if (nprod == 13) {
+            float rmax = 0.f;
+            for (int c = 0; c < k; ++c) rmax = fmaxf(rmax, fabsf(w[(size_t)r * k + c]));
+            if (rmax > 0.f && rmax < 0.0009765625f) ok = false;
+        }
         for (int c = 0; c < k; ++c) {
             const int kt = c >> 5, ks = (c >> 4) & 1, half = (c >> 3) & 1, e = c & 7;
             float v = w[(size_t)r * k + c];
             uint16_t* blk = out + ((size_t)panel * nkt + kt) * nplanes * 1024 + (size_t)(ks * 64 + half * 32 + l31) * 8 + e;
+            if (nprod == 13) {
+                if (!(fabsf(v) < 65504.0f)) ok = false;
+                const _Float16 y1 = (_Float16)v;
+                const _Float16 y2 = (_Float16)((v - (float)y1) * 2048.0f);
+                memcpy(&blk[0], &y1, 2);
+                memcpy(&blk[1024], &y2, 2);
+                continue;
+            }
             for (int pl = 0; pl < nplanes; ++pl) {
                 float back;
                 blk[(size_t)pl * 1024] = f32_to_bf16_rne(v, &back);
@@ -381,6 +462,7 @@ void gemm_split_weights_host(const float* w, int n, int k, int nplanes, uint16_t
             }
         }
     }
+    return ok;
 }
 
 // 1 = 128x128, 2 = 64x128, 5 = 160x128, 6 = 96x128, 7 = 64x256, 8 = 96x256 (M x N).  Measured with
@@ -402,7 +484,7 @@ int gemm_split_pick_split_k(int M, int N, int K, int nprod)
 {
     const double tiles = (double)((M + 63) / 64) * ((N + 127) / 128);
     if (tiles >= 1024) return 1;
-    const double pipe_us = 0.45 * (nprod == 6 ? 1.0 : nprod == 3 ? 0.6 : 0.4), lat_us = 0.6;
+    const double pipe_us = 0.45 * (nprod == 6 ? 1.0 : nprod == 3 || nprod == 13 ? 0.6 : 0.4), lat_us = 0.6;
     int best = 1;
     double best_t = 1e30;
     for (int split = 1; split <= ASR_MAX_SPLITK; split *= 2) {
@@ -424,6 +506,7 @@ hipError_t launch_gemm_split(const GemmArgs& a, int nprod, int tile_hint, hipStr
     if (a.epilogue == EPI_GLU && (a.N & 31)) return hipErrorInvalidValue;
     const int tile = tile_hint ? tile_hint : gemm_split_pick_tile(a.M, a.N, a.split_k, a.epilogue);
     switch (nprod) {
+        case 13: return launch_split_nprod<13>(a, tile, s);
         case 6: return launch_split_nprod<6>(a, tile, s);
         case 3: return launch_split_nprod<3>(a, tile, s);
         case 1: return launch_split_nprod<1>(a, tile, s);

@@ -365,6 +365,11 @@ __global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restr
     }
 }
 
+// A logit that is NaN or infinite (garbage in: NaN features, an overflowed layer) must not reach the selection code:
+// with NaN every comparison is false, no candidate would be chosen and the beam search would index memory with
+// whatever the output buffers held.  Finite values pass unchanged.
+__device__ __forceinline__ float finite_logit(float x) { return (x == x) ? fminf(fmaxf(x, -3.0e38f), 3.0e38f) : -3.0e38f; }
+
 // ---- model.test_output: log_softmax + top_k (model.py:345-347) -----------------------------------
 // One workgroup per row; the row lives in LDS (vocab*4 bytes).  Candidate order: value descending,
 // ties -> lower index (Q5).  z = (x - max) - log(sum exp(x - max)) exactly as tf.nn.log_softmax.
@@ -387,6 +392,7 @@ __global__ __launch_bounds__(256) void log_softmax_topk_kernel(const float* __re
     for (int i = tid; i < vocab; i += 256) {
         float v = x[i];
         for (int zz = 1; zz < nsplit; ++zz) v += x[zz * split_stride + i];
+        v = finite_logit(v);
         z[i] = v;
         m = fmaxf(m, v);
     }
@@ -421,6 +427,7 @@ __global__ __launch_bounds__(256) void log_softmax_topk_kernel(const float* __re
             for (int i = tid; i < vocab; i += 256) { const float v = z[i]; if (v > bv) { bv = v; bi = i; } }
         }
     }
+    if (tid < k) { values[(size_t)r * k + tid] = -INFINITY; indices[(size_t)r * k + tid] = 0; }   // ranks no candidate reaches (vocab < k only)
     __syncthreads();
     // rank the 4k candidates (value desc, index asc); entries with index 0x7fffffff are exhausted quarters
     const int nc = 4 * k;
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(256) void log_softmax_topk_reg_kernel(const float* 
             a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[j * 4 + c] = ok ? a[c] : -INFINITY;
+        for (int c = 0; c < 4; ++c) v[j * 4 + c] = ok ? finite_logit(a[c]) : -INFINITY;
     }
     float m = -INFINITY;
 #pragma unroll
@@ -509,6 +516,7 @@ __global__ __launch_bounds__(256) void log_softmax_topk_reg_kernel(const float* 
             }
         }
     }
+    if (tid < k) { values[(size_t)r * k + tid] = -INFINITY; indices[(size_t)r * k + tid] = 0; }   // ranks no candidate reaches
     __syncthreads();
     const int nc = 4 * k;
     if (tid < nc) {
@@ -546,7 +554,8 @@ __device__ void beam_prune_block(const float* scores, const int32_t* finished, c
         // scores*(1-f) + b*f with b = [0, -1e10, ...]  (model.py:238-240); tokens*(1-f) + 3*f (:253)
         const float cs = f ? (j == 0 ? 0.0f : -1e10f) : cand_scores[(size_t)r * k + j];
         L.ctok[c] = f ? 3 : cand_tokens[(size_t)r * k + j];
-        L.tot[c] = scores[r] + cs;
+        const float tot = scores[r] + cs;
+        L.tot[c] = (tot == tot) ? tot : -INFINITY;          // NaN has no rank: the counting below needs a total order
     }
     __syncthreads();
     for (int c = tid; c < kk; c += nth) {

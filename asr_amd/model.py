@@ -227,6 +227,10 @@ class Engine(object):
     def device_bytes(self):
         return int(lib.asr_device_bytes(self._h))
 
+    def range_retries(self):
+        """precision f32_f16x3: calls repeated on the bf16x6 kernels because an operand did not fit fp16."""
+        return int(lib.asr_range_retries(self._h))
+
 
 def visible_devices():
     return int(lib.asr_device_count())

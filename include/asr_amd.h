@@ -42,8 +42,16 @@ enum asr_ff_activation { ASR_FF_RELU = 0, ASR_FF_GLU = 1, ASR_FF_SIGMOID = 2, AS
  *               (terms below 2^-24 of the product dropped): f32-chain accuracy at 2.7x the matrix rate.  A layer
  *               whose input width is not a multiple of 32 runs on the F32 kernel in this and the next two modes.
  *   BF16X3      two terms each, three products (~2^-16 relative product error).
- *   BF16        operands rounded to bf16 (north_star's "bf16 MFMA" mode; tolerance stated in the tests). */
-enum asr_precision { ASR_PRECISION_F32 = 0, ASR_PRECISION_F32_BF16X6 = 1, ASR_PRECISION_BF16X3 = 2, ASR_PRECISION_BF16 = 3 };
+ *   BF16        operands rounded to bf16 (north_star's "bf16 MFMA" mode; tolerance stated in the tests).
+ *   F32_F16X3   float32 operands split as x = x1 + 2^-11 x2 with x1 = fp16(x), x2 = fp16(2^11 (x - x1)) (11 + 11 significand
+ *               bits); three fp16 matrix products per k-step, the 2^-11 group in an accumulator of its own: measured
+ *               against float64 its error is below the exact-f32 kernel's, at 5.3x the f32 matrix rate.  fp16 holds
+ *               magnitudes below 65504: weights are checked at asr_finalize_weights (a checkpoint that does not fit runs
+ *               as F32_BF16X6), activations while they are split - a call that meets one outside the range is repeated
+ *               on the F32_BF16X6 kernels before it returns, so results never depend on the range.
+ */
+enum asr_precision { ASR_PRECISION_F32 = 0, ASR_PRECISION_F32_BF16X6 = 1, ASR_PRECISION_BF16X3 = 2, ASR_PRECISION_BF16 = 3,
+                     ASR_PRECISION_F32_F16X3 = 4 };
 
 /* Model + search configuration: the YAML keys read by the inference graph
  * (model.py:19-45,434-442; config_template_*.yaml). */
@@ -194,6 +202,10 @@ int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, 
                     double* flops, double* bytes, int32_t* n_out);
 /* Device-memory footprint of the handle in bytes (weights + caches + workspaces). */
 int64_t asr_device_bytes(const asr_handle* h);
+
+/* ASR_PRECISION_F32_F16X3 only: how many calls on this handle were repeated on the F32_BF16X6 kernels because an operand
+ * did not fit fp16 (diagnostics; the results of such calls are those of F32_BF16X6).  No counterpart in the reference. */
+int64_t asr_range_retries(const asr_handle* h);
 
 /* Host utility, no GPU involved: crc32c (Castagnoli) continued from `crc` (0 to start).  The checksum TensorFlow
  * stores per tensor and per index block in the V2 checkpoints that `saver.restore` (evaluate.py:36) reads and

@@ -18,7 +18,7 @@ from tests.helpers import product_config, rel_err, tiny_config, tiny_inputs
 
 pytestmark = pytest.mark.gpu
 
-DENSE_TOL = {'f32': 2e-6, 'f32_bf16x6': 2e-6, 'bf16x3': 1e-4, 'bf16': 2e-2}
+DENSE_TOL = {'f32': 2e-6, 'f32_bf16x6': 2e-6, 'f32_f16x3': 2e-6, 'bf16x3': 1e-4, 'bf16': 2e-2}
 
 
 def _engine(ocfg, precision, W=None):
@@ -62,20 +62,62 @@ def test_dense_modes(mode_eng, m, n, k, split):
     assert rel_err(_dense(eng, x, w, None, split), want - b) < DENSE_TOL[mode]
 
 
-def test_bf16x6_error_not_worse_than_exact_f32():
-    """The split-product path must be as accurate as the exact-f32 MFMA path (rms error vs float64)."""
+def test_split_modes_error_not_worse_than_exact_f32():
+    """The split-product paths must be as accurate as the exact-f32 MFMA path (rms error vs float64)."""
     rng = np.random.default_rng(5)
     x = rng.standard_normal((640, 1024)).astype(np.float32)
     w = rng.uniform(-0.05, 0.05, (1024, 1024)).astype(np.float32)
     want = x.astype(np.float64) @ w.astype(np.float64).T
     rms = {}
-    for mode in ('f32', 'f32_bf16x6'):
+    for mode in ('f32', 'f32_bf16x6', 'f32_f16x3'):
         e = _engine(tiny_config(), mode)
         try:
             rms[mode] = float(np.sqrt(np.mean((_dense(e, x, w, None).astype(np.float64) - want) ** 2)))
         finally:
             e.close()
     assert rms['f32_bf16x6'] <= 1.5 * rms['f32'], rms
+    assert rms['f32_f16x3'] <= 1.5 * rms['f32'], rms
+
+
+def test_f16x3_out_of_range_operands_are_redone_on_bf16x6():
+    """fp16 holds magnitudes below 65504: an activation or weight beyond that must not change the result - the call is
+    repeated on the bf16x6 kernels (asr_range_retries counts it)."""
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((70, 256)).astype(np.float32)
+    w = (rng.standard_normal((96, 256)) / 16).astype(np.float32)
+    e = _engine(tiny_config(), 'f32_f16x3')
+    try:
+        assert rel_err(_dense(e, x, w, None), x.astype(np.float64) @ w.astype(np.float64).T) < 2e-6
+        assert e.range_retries() == 0
+        xb = x.copy(); xb[3, 7] = 1.0e5; xb[69, 255] = -7.0e4          # activations outside fp16
+        assert rel_err(_dense(e, xb, w, None), xb.astype(np.float64) @ w.astype(np.float64).T) < 2e-6
+        assert e.range_retries() == 1
+        wb = w.copy(); wb[95, 0] = 3.0e5                                 # a weight outside fp16
+        assert rel_err(_dense(e, x, wb, None), x.astype(np.float64) @ wb.astype(np.float64).T) < 2e-6
+        assert e.range_retries() == 2
+        xs = x * 1.0e-6                                                  # rows so small that fp16 would lose relative accuracy
+        assert rel_err(_dense(e, xs, w, None), xs.astype(np.float64) @ w.astype(np.float64).T) < 2e-6
+        assert e.range_retries() == 3
+        xz = x.copy(); xz[5:9] = 0.0                                     # all-zero rows (padding) are exact, not "too small"
+        assert rel_err(_dense(e, xz, w, None), xz.astype(np.float64) @ w.astype(np.float64).T) < 2e-6
+        assert e.range_retries() == 3
+    finally:
+        e.close()
+
+
+def test_f16x3_decode_with_out_of_range_features_matches_oracle():
+    """Features scaled by 1e6 leave fp16's range in the first layer: the decode must still give the oracle's hypotheses."""
+    ocfg = tiny_config()
+    W = O.random_weights(ocfg, seed=2, bias_scale=0.1)
+    X = tiny_inputs((60, 90, 75), seed=12) * np.float32(1.0e6)
+    eng = _engine(ocfg, 'f32_f16x3', W)
+    try:
+        want = O.build_test_model(X, W, ocfg, num_gpus=1, algo='kv')
+        Y = eng.decode(X)
+        assert eng.range_retries() == 1
+        assert Y.shape == want.shape and np.array_equal(Y, want)
+    finally:
+        eng.close()
 
 
 def test_dense_glu_modes(mode_eng):
@@ -103,12 +145,13 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize('mode', ['f32_bf16x6', 'f32_f16x3'])
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
-def test_bf16x6_hypotheses_and_logits_match_oracle(case):
+def test_split_modes_hypotheses_and_logits_match_oracle(case, mode):
     ocfg = tiny_config(**case['cfg'])
     W = O.random_weights(ocfg, seed=case['seed'], bias_scale=0.1)
     X = tiny_inputs(case['lens'], seed=case['seed'] + 10)
-    eng = _engine(ocfg, 'f32_bf16x6', W)
+    eng = _engine(ocfg, mode, W)
     try:
         Wc = O.cast_weights(W, np.float64)
         enc64, _ = O.encoder(X.astype(np.float64), Wc, ocfg)
@@ -119,6 +162,29 @@ def test_bf16x6_hypotheses_and_logits_match_oracle(case):
         Y, tr = eng.decode_trace(X, 2)
         assert Y.shape == want.shape and np.array_equal(Y, want)
         assert rel_err(tr['logits'][0], trace['logits'][0]) < 1e-3      # north_star bar; observed ~1e-5
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize('mode', ['f32', 'f32_bf16x6', 'f32_f16x3'])
+def test_nan_and_inf_features_do_not_poison_the_beam_search(mode):
+    """Garbage in one utterance (NaN / inf features) must stay in that utterance: the call returns normally, every token
+    is a vocabulary id, and the clean utterance of the same batch decodes as it does without the garbage (NaN logits
+    once left the top-k without a candidate and the beam search indexed memory with stale values)."""
+    ocfg = tiny_config(beam_size=3, max_target_length=12)
+    W = O.random_weights(ocfg, seed=1, bias_scale=0.1)
+    X = tiny_inputs((60, 60, 60), seed=2)
+    want = O.build_test_model(X, W, ocfg, num_gpus=1, algo='kv')
+    Xb = X.copy()
+    Xb[1, 5, 7] = np.nan
+    Xb[2, 9, 3] = np.inf
+    eng = _engine(ocfg, mode, W)
+    try:
+        Y = eng.decode(Xb)
+        assert Y.shape[0] == 3 and Y.min() >= 0 and Y.max() < ocfg.dst_vocab_size
+        n = min(Y.shape[1], want.shape[1])
+        assert np.array_equal(Y[0, :n], want[0, :n])
+        assert np.array_equal(eng.decode(X), want)                # and the handle is still good
     finally:
         eng.close()
 

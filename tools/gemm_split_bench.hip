@@ -54,7 +54,7 @@ int main(int argc, char** argv)
         const size_t cnt = (size_t)s.N * s.K;
         (void)cnt;
         planes.resize(gemm_split_weight_elems(s.N, s.K, npl));
-        gemm_split_weights_host(hW.data(), s.N, s.K, npl, planes.data());
+        gemm_split_weights_host(hW.data(), s.N, s.K, nprod, planes.data());
         CK(hipMemcpy(Wp, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
         const bool dec = s.M <= 640;
         const int ldc = s.epi == EPI_GLU ? s.N / 2 : s.N;
