@@ -38,7 +38,11 @@
 #include "gemm_epilogue.h"
 #include <math.h>
 #include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -434,35 +438,52 @@ bool gemm_split_weights_host(const float* w, int n, int k, int nprod, uint16_t* 
 {
     const int nplanes = gemm_split_planes(nprod);
     const int nkt = k / 32;
-    bool ok = true;
-    memset(out, 0, gemm_split_weight_elems(n, k, nplanes) * sizeof(uint16_t));
-    for (int r = 0; r < n; ++r) {
-        const int panel = r >> 5, l31 = r & 31;
-        if (nprod == 13) {
-            float rmax = 0.f;
-            for (int c = 0; c < k; ++c) rmax = fmaxf(rmax, fabsf(w[(size_t)r * k + c]));
-            if (rmax > 0.f && rmax < 0.0009765625f) ok = false;
-        }
-        for (int c = 0; c < k; ++c) {
-            const int kt = c >> 5, ks = (c >> 4) & 1, half = (c >> 3) & 1, e = c & 7;
-            float v = w[(size_t)r * k + c];
-            uint16_t* blk = out + ((size_t)panel * nkt + kt) * nplanes * 1024 + (size_t)(ks * 64 + half * 32 + l31) * 8 + e;
+    std::atomic<bool> ok{true};
+    const int npanels = (n + 31) / 32;
+    if (n & 31) memset(out + (size_t)(npanels - 1) * nkt * nplanes * 1024, 0, (size_t)nkt * nplanes * 1024 * sizeof(uint16_t));
+    auto pack_rows = [&](int r0, int r1) {
+        for (int r = r0; r < r1; ++r) {
+            const int panel = r >> 5, l31 = r & 31;
             if (nprod == 13) {
-                if (!(fabsf(v) < 65504.0f)) ok = false;
-                const _Float16 y1 = (_Float16)v;
-                const _Float16 y2 = (_Float16)((v - (float)y1) * 2048.0f);
-                memcpy(&blk[0], &y1, 2);
-                memcpy(&blk[1024], &y2, 2);
-                continue;
+                float rmax = 0.f;
+                for (int c = 0; c < k; ++c) rmax = fmaxf(rmax, fabsf(w[(size_t)r * k + c]));
+                if (rmax > 0.f && rmax < 0.0009765625f) ok = false;
             }
-            for (int pl = 0; pl < nplanes; ++pl) {
-                float back;
-                blk[(size_t)pl * 1024] = f32_to_bf16_rne(v, &back);
-                v = v - back;
+            for (int c = 0; c < k; ++c) {
+                const int kt = c >> 5, ks = (c >> 4) & 1, half = (c >> 3) & 1, e = c & 7;
+                float v = w[(size_t)r * k + c];
+                uint16_t* blk = out + ((size_t)panel * nkt + kt) * nplanes * 1024 + (size_t)(ks * 64 + half * 32 + l31) * 8 + e;
+                if (nprod == 13) {
+                    if (!(fabsf(v) < 65504.0f)) ok = false;
+                    const _Float16 y1 = (_Float16)v;
+                    const _Float16 y2 = (_Float16)((v - (float)y1) * 2048.0f);
+                    memcpy(&blk[0], &y1, 2);
+                    memcpy(&blk[1024], &y2, 2);
+                    continue;
+                }
+                for (int pl = 0; pl < nplanes; ++pl) {
+                    float back;
+                    blk[(size_t)pl * 1024] = f32_to_bf16_rne(v, &back);
+                    v = v - back;
+                }
             }
         }
+    };
+    // rows are independent (a row writes its own 16-byte pieces): panels dealt to a few host threads
+    const size_t work = (size_t)n * k;
+    const int nthreads = work < ((size_t)1 << 20) ? 1 : (int)std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+    if (nthreads <= 1) {
+        pack_rows(0, n);
+    } else {
+        std::vector<std::thread> th;
+        const int per = ((npanels + nthreads - 1) / nthreads) * 32;
+        for (int t = 0; t < nthreads; ++t) {
+            const int r0 = std::min(n, t * per), r1 = std::min(n, (t + 1) * per);
+            if (r0 < r1) th.emplace_back(pack_rows, r0, r1);
+        }
+        for (auto& x : th) x.join();
     }
-    return ok;
+    return ok.load();
 }
 
 // 1 = 128x128, 2 = 64x128, 5 = 160x128, 6 = 96x128, 7 = 64x256, 8 = 96x256 (M x N).  Measured with

@@ -41,7 +41,7 @@ PRECISION_INFO = {
 }
 
 
-def bench_config(beam=10, mtl=200, precision='f32_bf16x6'):
+def bench_config(beam=10, mtl=200, precision='f32_f16x3'):
     from asr_amd.utils import AttrDict
     return AttrDict({
         'model': 'Transformer', 'dst_vocab_size': 3900, 'hidden_units': 1024, 'scale_embedding': True,
@@ -108,7 +108,7 @@ def main():
     ap.add_argument('--max-target-length', type=int, default=200)
     ap.add_argument('--cpu-sample-utts', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_bf16x6'), choices=sorted(PRECISION_INFO))
+    ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_f16x3'), choices=sorted(PRECISION_INFO))
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
