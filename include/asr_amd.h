@@ -69,7 +69,7 @@ typedef struct asr_config {
     float   lp_alpha;                    /* test.lp_alpha                                 */
     int32_t device;                      /* HIP device ordinal this handle lives on       */
     int32_t precision;                   /* enum asr_precision (build extension; YAML key test.precision; the Python host's default
-                                            is F32_BF16X6, a zeroed struct means F32) */
+                                            is F32_F16X3, a zeroed struct means F32) */
     int32_t sub_batches;                 /* 1 = beam-search the batch as one run of kernels, 2 = as two independent halves on
                                             two streams (same results: utterances are independent), 0 = env
                                             ASR_AMD_SUBBATCH or automatic (two halves from 320 beam rows);
