@@ -420,6 +420,11 @@ int decode_splits(const asr_handle* h, int R, int* s_qkv, int* s_proj, int* s_ff
     *s_qkv = gemm_pick_split_k(R, 3 * h->H, h->H, gemm_nprod(h, h->H));
     *s_proj = gemm_pick_split_k(R, h->H, h->H, gemm_nprod(h, h->H));
     *s_ffn2 = gemm_pick_split_k(R, h->H, h->F, gemm_nprod(h, h->F));
+    if (const char* e = getenv("ASR_AMD_SPLITS")) {                  // development: "qkv,proj,ffn2"
+        int a = 0, b = 0, c = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 1 && b >= 1 && c >= 1 && a <= ASR_MAX_SPLITK && b <= ASR_MAX_SPLITK &&
+            c <= ASR_MAX_SPLITK) { *s_qkv = a; *s_proj = b; *s_ffn2 = c; }
+    }
     return 0;
 }
 

@@ -498,14 +498,15 @@ int gemm_split_pick_tile(int M, int N, int split_k, int epilogue)
     return tiles >= 2048 ? 7 : 2;
 }
 
-// K-slices for the decode-time projections (64 x 128 tiles): a k-tile costs a workgroup about 0.6 us while it waits on
-// its own loads and barrier, about 0.45 us of matrix pipe when workgroups queue on a CU; every slab costs one more write
-// + read of M x N floats by the consumer.  Constants fitted to tools/gemm_split_bench.hip.
+// K-slices for the decode-time projections (64 x 128 tiles): a k-tile costs a workgroup about 0.3 us while it waits on
+// its own loads and barrier, about 0.45 us (six products) of matrix pipe when workgroups queue on a CU; every slab costs
+// one more write + read of M x N floats by the consumer.  Constants fitted to tools/gemm_split_bench.hip and to an
+// end-to-end sweep of the bench (tools/splits_sweep.sh: 320-row halves, fp16x3: QKV 2, projections 4, FFN2 4).
 int gemm_split_pick_split_k(int M, int N, int K, int nprod)
 {
     const double tiles = (double)((M + 63) / 64) * ((N + 127) / 128);
     if (tiles >= 1024) return 1;
-    const double pipe_us = 0.45 * (nprod == 6 ? 1.0 : nprod == 3 || nprod == 13 ? 0.6 : 0.4), lat_us = 0.6;
+    const double pipe_us = 0.45 * (nprod == 6 ? 1.0 : nprod == 3 || nprod == 13 ? 0.6 : 0.4), lat_us = 0.3;
     int best = 1;
     double best_t = 1e30;
     for (int split = 1; split <= ASR_MAX_SPLITK; split *= 2) {
