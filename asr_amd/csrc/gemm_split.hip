@@ -72,12 +72,15 @@ __device__ __forceinline__ f32x16 mma32(const u32x4& a, const u32x4& b, const f3
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int MI, int NI, int EPI, int NPROD>
-__global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
+template <int MI, int NI, int NW, int EPI, int NPROD>
+__global__ __launch_bounds__(NW * 64) void gemm_split_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
 {
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves side by side");
+    constexpr int FPT = 2048 / (NW * 64);              // floats of a 64 x 32 A pass per thread: 8 (4 waves) or 4 (8 waves)
+    constexpr int LPT = FPT / 4, PAIRS = FPT / 2;      // 16-byte loads / float pairs per thread per pass
     constexpr bool F16 = SplitMode<NPROD>::F16;
     constexpr int NPL = SplitMode<NPROD>::NPL;
-    constexpr int WN = NI * 32, BM = MI * 32, BN = 4 * WN;
+    constexpr int WN = NI * 32, BM = MI * 32, BN = NW * WN;
     constexpr int A_LD = (BM + 63) / 64;               // staging passes of 64 rows
     constexpr int AR = A_LD * 64;                      // LDS rows (tile padded to whole passes: every staging load and
                                                        // store is unconditional, so the compiler's wait counts are exact)
@@ -123,12 +126,12 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
             }
     float amax = 0.0f;                                  // fp16x3: largest |activation| this thread has split
 
-    // A staging: thread -> row (tid >> 2) + 64 i, 8 floats at k = 8 (tid & 3).  Rows past M are clamped (their products
-    // land in C rows that are never stored).
-    const int srow = tid >> 2, sch = tid & 3;
+    // A staging: thread -> row tid / (32 / FPT) + 64 i, FPT floats at k = FPT (tid % (32 / FPT)).  Rows past M are clamped
+    // (their products land in C rows that are never stored).
+    const int srow = tid / (32 / FPT), sch = tid % (32 / FPT);
     const float* arow[A_LD];
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) arow[i] = p.A + (size_t)min(m0 + srow + 64 * i, p.M - 1) * p.lda + sch * 8;
+    for (int i = 0; i < A_LD; ++i) arow[i] = p.A + (size_t)min(m0 + srow + 64 * i, p.M - 1) * p.lda + sch * FPT;
     // W fragments: panel (n0 + wn0) / 32 + n of this wave (clamped past the last panel: columns never stored)
     const int npanels = (p.N + 31) >> 5;
     const u32x4* wfrag[NI];
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
         wfrag[n] = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)min(((n0 + wn0) >> 5) + n, npanels - 1) * nkt * (NPL * 128) + lane;
 
     // register sets (set = k-tile parity): A as loaded, W as the MFMA consumes it
-    f32x4 ra[2][A_LD][2];
+    f32x4 ra[2][A_LD][LPT];
     u32x4 rw[2][2][NPL][NI];                           // [set][k-step][plane][n]
     auto ktile_k0 = [&](int t) { return kbeg + (t < nk ? t : 0) * SBK; };                       // past the slice: a harmless re-read
     auto ktile_woff = [&](int t) { return (size_t)(kt0 + (t < nk ? t : 0)) * (NPL * 128); };
@@ -145,10 +148,9 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
         constexpr int S = decltype(setc)::value;
         const int k0 = ktile_k0(t);
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            ra[S][i][0] = *reinterpret_cast<const f32x4*>(arow[i] + k0);
-            ra[S][i][1] = *reinterpret_cast<const f32x4*>(arow[i] + k0 + 4);
-        }
+        for (int i = 0; i < A_LD; ++i)
+#pragma unroll
+            for (int hh = 0; hh < LPT; ++hh) ra[S][i][hh] = *reinterpret_cast<const f32x4*>(arow[i] + k0 + 4 * hh);
     };
     auto gload_w = [&](auto setc, int t, int ks) {
         constexpr int S = decltype(setc)::value;
@@ -161,18 +163,18 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
                 if (ks == 0) rw[S][0][pl][n] = v; else rw[S][1][pl][n] = v;
             }
     };
-    u32x4 pieces[A_LD][NPL];
+    uint32_t pieces[A_LD][NPL][PAIRS];
     f32x2 rest[A_LD];                                  // what is left of the pair being split
-    // A staging, in small steps (so that they can be dealt out between MFMAs): per pass of 64 rows, for each of the 4
-    // pairs of floats: (pair, 0) = plane 0 and the remainder, (pair, 1) = the other planes; then one store group
-    constexpr int APASS = 4 * 2 + 1;
+    // A staging, in small steps (so that they can be dealt out between MFMAs): per pass of 64 rows, for each of the
+    // thread's pairs of floats: (pair, 0) = plane 0 and the remainder, (pair, 1) = the other planes; then one store group
+    constexpr int APASS = PAIRS * 2 + 1;
     auto astage = [&](auto setc, int buf, int op) {
         constexpr int S = decltype(setc)::value;
         u32x4* As = lds + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
+            for (int pr = 0; pr < PAIRS; ++pr) {
                 if (op == i * APASS + 2 * pr) {
                     const f32x4& x = ra[S][i][pr >> 1];
                     f32x2 v = {x[2 * (pr & 1)], x[2 * (pr & 1) + 1]};
@@ -201,10 +203,19 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
                     }
                 }
             }
-            if (op == i * APASS + 8) {
+            if (op == i * APASS + 2 * PAIRS) {
                 const int row = srow + 64 * i;
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) As[(pl * AR + row) * 4 + (sch ^ ((row >> 2) & 3))] = pieces[i][pl];
+                for (int pl = 0; pl < NPL; ++pl) {
+                    if constexpr (PAIRS == 4) {
+                        As[(pl * AR + row) * 4 + (sch ^ ((row >> 2) & 3))] =
+                            u32x4{pieces[i][pl][0], pieces[i][pl][1], pieces[i][pl][2], pieces[i][pl][3]};
+                    } else {                           // half a 16-byte chunk per thread
+                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                        u32x2* dst = reinterpret_cast<u32x2*>(&As[(pl * AR + row) * 4 + ((sch >> 1) ^ ((row >> 2) & 3))]) + (sch & 1);
+                        *dst = u32x2{pieces[i][pl][0], pieces[i][pl][1]};
+                    }
+                }
             }
         }
     };
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
     constexpr int NF = NPL * MI;                         // A fragment reads per k-step
     constexpr int NA = A_LD * APASS;                     // A staging ops per k-tile
     constexpr int NWL = NPL * NI;                        // W loads per k-step
-    constexpr int NAL = A_LD * 2;                        // A loads per k-tile
+    constexpr int NAL = A_LD * LPT;                      // A loads per k-tile
     int g_k0 = 0;
     size_t g_woff = 0;
     auto side_gload_a = [&](auto setc, int op) {
@@ -246,8 +257,8 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
 #pragma unroll
         for (int i = 0; i < A_LD; ++i)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-                if (op == i * 2 + hh) ra[S][i][hh] = *reinterpret_cast<const f32x4*>(arow[i] + g_k0 + 4 * hh);
+            for (int hh = 0; hh < LPT; ++hh)
+                if (op == i * LPT + hh) ra[S][i][hh] = *reinterpret_cast<const f32x4*>(arow[i] + g_k0 + 4 * hh);
     };
     auto side_gload_w = [&](auto setc, auto ksc, int op) {             // op = pl * NI + n
         constexpr int S = decltype(setc)::value;
@@ -353,18 +364,18 @@ __global__ __launch_bounds__(256) void gemm_split_nt_kernel(GemmArgs p, int nt_m
     gemm_store_tile<EPI, MI, NI>(p, acc, m0, n0, 0, wn0, z, lane);
 }
 
-template <int MI, int NI, int EPI, int NPROD>
+template <int MI, int NI, int NW, int EPI, int NPROD>
 hipError_t launch_split_tile(const GemmArgs& a, hipStream_t s)
 {
     constexpr int NPL = SplitMode<NPROD>::NPL;
-    constexpr int BM = MI * 32, BN = 4 * NI * 32;
+    constexpr int BM = MI * 32, BN = NW * NI * 32;
     constexpr int AR = (BM + 63) / 64 * 64;
     const int nt_m = (a.M + BM - 1) / BM, nt_n = (a.N + BN - 1) / BN;
     const int split = a.split_k < 1 ? 1 : a.split_k;
     int kchunk = (a.K + split - 1) / split;
     kchunk = (kchunk + SBK - 1) / SBK * SBK;
     const size_t lds = (size_t)2 * NPL * AR * 4 * sizeof(u32x4);
-    auto kern = gemm_split_nt_kernel<MI, NI, EPI, NPROD>;
+    auto kern = gemm_split_nt_kernel<MI, NI, NW, EPI, NPROD>;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -373,7 +384,7 @@ hipError_t launch_split_tile(const GemmArgs& a, hipStream_t s)
         if (e != hipSuccess) return e;
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nt_m * nt_n, split, 1), dim3(256), lds, s, a, nt_m, nt_n, kchunk);
+    hipLaunchKernelGGL(kern, dim3(nt_m * nt_n, split, 1), dim3(NW * 64), lds, s, a, nt_m, nt_n, kchunk);
     return hipGetLastError();
 }
 
@@ -381,12 +392,11 @@ template <int EPI, int NPROD>
 hipError_t launch_split_epi(const GemmArgs& a, int tile, hipStream_t s)
 {
     switch (tile) {
-        case 1: return launch_split_tile<4, 1, EPI, NPROD>(a, s);     // 128 x 128
-        case 5: return launch_split_tile<5, 1, EPI, NPROD>(a, s);     // 160 x 128
-        case 6: return launch_split_tile<3, 1, EPI, NPROD>(a, s);     // 96 x 128
-        case 7: return launch_split_tile<2, 2, EPI, NPROD>(a, s);     // 64 x 256
-        case 8: return launch_split_tile<3, 2, EPI, NPROD>(a, s);     // 96 x 256
-        default: return launch_split_tile<2, 1, EPI, NPROD>(a, s);    // 64 x 128
+        case 1: return launch_split_tile<4, 1, 4, EPI, NPROD>(a, s);     // 128 x 128
+        case 5: return launch_split_tile<5, 1, 4, EPI, NPROD>(a, s);     // 160 x 128
+        case 7: return launch_split_tile<2, 2, 4, EPI, NPROD>(a, s);     // 64 x 256, 4 waves of 64 columns
+        case 9: return launch_split_tile<2, 1, 8, EPI, NPROD>(a, s);     // 64 x 256, 8 waves of 32 columns
+        default: return launch_split_tile<2, 1, 4, EPI, NPROD>(a, s);    // 64 x 128
     }
 }
 
@@ -486,26 +496,29 @@ bool gemm_split_weights_host(const float* w, int n, int k, int nprod, uint16_t* 
     return ok.load();
 }
 
-// 1 = 128x128, 2 = 64x128, 5 = 160x128, 6 = 96x128, 7 = 64x256, 8 = 96x256 (M x N).  Measured with
-// tools/gemm_split_bench.hip on MI355X: 64-row tiles win at every shape of the model, the 640 decode rows as well as the
-// 21376 encoder rows (several workgroups per CU hide each other's barrier and load latencies; under a dense MFMA load the
-// chip lowers its clock, so the taller tiles' better MFMA-per-byte ratio does not show as wall time).  Encoder-sized
-// problems take 256 columns per workgroup (half the A-splitting work per MFMA: +5 %).
-int gemm_split_pick_tile(int M, int N, int split_k, int epilogue)
+// 1 = 128x128, 2 = 64x128, 5 = 160x128, 7 = 64x256 as 4 waves of 64 columns, 9 = 64x256 as 8 waves of 32 columns (M x N).
+// Measured with tools/gemm_split_bench.hip on MI355X: 64-row tiles win at every shape of the model, the 640 decode rows as
+// well as the 21376 encoder rows (several workgroups per CU hide each other's barrier and load latencies; under a dense
+// MFMA load the chip lowers its clock, so the taller tiles' better MFMA-per-byte ratio does not show as wall time).  The
+// 8-wave workgroup splits an A tile once for 256 columns instead of 128 (the split is ~15 % of the fp16x3 kernel's time) at
+// the same number of waves per CU: 5-10 % faster wherever there are enough 256-column tiles to go round, i.e. everywhere
+// but the 1024 x 1024 projections of the decode rows.
+int gemm_split_pick_tile(int M, int N, int K, int split_k, int epilogue)
 {
     (void)split_k; (void)epilogue;
-    const long tiles = (long)((M + 63) / 64) * ((N + 255) / 256);
-    return tiles >= 2048 ? 7 : 2;
+    const long t256 = (long)((M + 63) / 64) * ((N + 255) / 256);
+    return t256 * std::max(1, K / 1024) >= 64 ? 9 : 2;
 }
 
-// K-slices for the decode-time projections (64 x 128 tiles): a k-tile costs a workgroup about 0.3 us while it waits on
-// its own loads and barrier, about 0.45 us (six products) of matrix pipe when workgroups queue on a CU; every slab costs
-// one more write + read of M x N floats by the consumer.  Constants fitted to tools/gemm_split_bench.hip and to an
-// end-to-end sweep of the bench (tools/splits_sweep.sh: 320-row halves, fp16x3: QKV 2, projections 4, FFN2 4).
+// K-slices for the decode-time projections: a k-tile costs a workgroup about 0.3 us while it waits on its own loads and
+// barrier, about 0.45 us (six products) of matrix pipe when workgroups queue on a CU; every slab costs one more write +
+// read of M x N floats by the consumer.  Constants fitted to tools/gemm_split_bench.hip and to an end-to-end sweep of the
+// bench (tools/splits_sweep.sh).
 int gemm_split_pick_split_k(int M, int N, int K, int nprod)
 {
-    const double tiles = (double)((M + 63) / 64) * ((N + 127) / 128);
-    if (tiles >= 1024) return 1;
+    const int bn = gemm_split_pick_tile(M, N, K, 1, 0) == 9 ? 256 : 128;
+    const double tiles = (double)((M + 63) / 64) * ((N + bn - 1) / bn);
+    if (tiles * (bn / 128) >= 1024) return 1;
     const double pipe_us = 0.45 * (nprod == 6 ? 1.0 : nprod == 3 || nprod == 13 ? 0.6 : 0.4), lat_us = 0.3;
     int best = 1;
     double best_t = 1e30;
@@ -526,7 +539,7 @@ hipError_t launch_gemm_split(const GemmArgs& a, int nprod, int tile_hint, hipStr
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Wp)) & 15) return hipErrorInvalidValue;
     if (a.split_k > 1 && a.epilogue != EPI_PARTIAL) return hipErrorInvalidValue;
     if (a.epilogue == EPI_GLU && (a.N & 31)) return hipErrorInvalidValue;
-    const int tile = tile_hint ? tile_hint : gemm_split_pick_tile(a.M, a.N, a.split_k, a.epilogue);
+    const int tile = tile_hint ? tile_hint : gemm_split_pick_tile(a.M, a.N, a.K, a.split_k, a.epilogue);
     switch (nprod) {
         case 13: return launch_split_nprod<13>(a, tile, s);
         case 6: return launch_split_nprod<6>(a, tile, s);

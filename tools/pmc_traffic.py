@@ -33,10 +33,10 @@ def bench_class(kernel):
     m = re.search(r'gemm_f32_nt_kernel<(\d+), (\d+), \d+, \d+, (\d)(?:, (\w+))?>', kernel)
     if m:
         return 'gemm_f32_nt<%s,%s,%s>' % (m.group(1), m.group(2), EPI.get(m.group(3), 'ACT'))
-    m = re.search(r'gemm_split_nt_kernel<(\d+), (\d+), (\d), (\d+)>', kernel)       # <MI, NI, EPI, NPROD>: 32 MI x 128 NI tile
+    m = re.search(r'gemm_split_nt_kernel<(\d+), (\d+), (\d), (\d), (\d+)>', kernel)   # <MI, NI, NW, EPI, NPROD>: 32 MI x 32 NI NW tile
     if m:
-        base = {'13': 'gemm_f16x3_nt', '6': 'gemm_bf16x6_nt', '3': 'gemm_bf16x3_nt', '1': 'gemm_bf16_nt'}[m.group(4)]
-        return '%s<%d,%d,%s>' % (base, 32 * int(m.group(1)), 128 * int(m.group(2)), EPI.get(m.group(3), 'ACT'))
+        base = {'13': 'gemm_f16x3_nt', '6': 'gemm_bf16x6_nt', '3': 'gemm_bf16x3_nt', '1': 'gemm_bf16_nt'}[m.group(5)]
+        return '%s<%d,%d,%s>' % (base, 32 * int(m.group(1)), 32 * int(m.group(2)) * int(m.group(3)), EPI.get(m.group(4), 'ACT'))
     m = re.search(r'::(\w+?)(?:_kernel)?(?:<[^>]*>)?\(', kernel) or re.search(r'(\w+)', kernel)
     return RENAME.get(m.group(1), m.group(1))
 
