@@ -17,7 +17,8 @@
 // large ones).  What it costs is range: an operand of magnitude >= 65504 does not fit x1, and below 2^-14 x1 and x2 sink
 // into fp16's subnormals (absolute error <= 2^-36 per element: nothing beside ordinary elements, but a relative loss for
 // a row that is that small throughout).  Weights are checked row by row when they are packed; activations are checked as
-// they are split (a thread's largest magnitude must lie in [2^-10, 65504) or be 0), and a kernel that meets one outside
+// they are split (a row's largest magnitude over the workgroup's K slice must lie in [2^-10, 65504) or be 0), and a kernel
+// that meets one outside
 // sets GemmArgs.range_flag - the caller must then discard the result (the engine repeats the call on the bf16x6 kernels).
 //
 // Replaces utils.dense (transformer/utils.py:546-557) and the GLU pairing of utils.py:559-561.
@@ -357,8 +358,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_split_nt_kernel(GemmArgs p, int 
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int n = 0; n < NI; ++n) acc[i][n] += acc2[i][n] * (1.0f / F16X3_SCALE);
-        // outside fp16's range, or a row piece so small (largest of >= 32 values below 2^-10) that x1 / x2 fall into fp16's
-        // subnormals and lose relative accuracy: the caller repeats the call on the bf16x6 kernels
+        // The 32 / FPT neighbouring lanes that stage one A row hold, together, that row's largest magnitude over the
+        // workgroup's whole K slice (>= 128 values).  Outside fp16's range, or so small throughout (below 2^-10, not 0) that
+        // x1 / x2 fall into fp16's subnormals and lose relative accuracy: the caller repeats the call on the bf16x6 kernels.
+        // (Judging single threads' 16-value pieces instead would trip on sparse rows, e.g. ReLU outputs.)
+#pragma unroll
+        for (int o = 1; o < 32 / FPT; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
         if ((!(amax < F16_MAX) || (amax > 0.0f && amax < F16_TINY)) && p.range_flag) atomicOr(p.range_flag, 1);
     }
     gemm_store_tile<EPI, MI, NI>(p, acc, m0, n0, 0, wn0, z, lane);

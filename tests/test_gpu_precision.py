@@ -98,6 +98,9 @@ def test_f16x3_out_of_range_operands_are_redone_on_bf16x6():
         xs = x * 1.0e-6                                                  # rows so small that fp16 would lose relative accuracy
         assert rel_err(_dense(e, xs, w, None), xs.astype(np.float64) @ w.astype(np.float64).T) < 2e-6
         assert e.range_retries() == 3
+        xr = np.maximum(x, 0.0); xr[xr < 0.05] *= 1.0e-3                 # sparse rows with tiny entries (ReLU-like): fine
+        assert rel_err(_dense(e, xr, w, None), xr.astype(np.float64) @ w.astype(np.float64).T) < 2e-6
+        assert e.range_retries() == 3
         xz = x.copy(); xz[5:9] = 0.0                                     # all-zero rows (padding) are exact, not "too small"
         assert rel_err(_dense(e, xz, w, None), xz.astype(np.float64) @ w.astype(np.float64).T) < 2e-6
         assert e.range_retries() == 3
