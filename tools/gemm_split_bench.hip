@@ -21,7 +21,7 @@ int main(int argc, char** argv)
     const int only_tile = argc > 4 ? atoi(argv[4]) : 0, only_split = argc > 5 ? atoi(argv[5]) : 0;
     std::vector<Shape> shapes = {
         {"qkv   ", 640, 3072, 1024, EPI_PARTIAL}, {"proj  ", 640, 1024, 1024, EPI_PARTIAL},
-        {"glu   ", 640, 8192, 1024, EPI_GLU},     {"ffn2  ", 640, 1024, 4096, EPI_PARTIAL},
+        {"glu   ", 640, 8192, 1024, EPI_GLU},     {"xgluP ", 640, 8192, 1024, EPI_PARTIAL}, {"xgluB ", 640, 8192, 1024, EPI_BIAS},     {"ffn2  ", 640, 1024, 4096, EPI_PARTIAL},
         {"logits", 640, 3900, 1024, EPI_PARTIAL},
         {"hqkv  ", 320, 3072, 1024, EPI_PARTIAL}, {"hproj ", 320, 1024, 1024, EPI_PARTIAL},
         {"hglu  ", 320, 8192, 1024, EPI_GLU},     {"hffn2 ", 320, 1024, 4096, EPI_PARTIAL},
