@@ -397,9 +397,11 @@ template <int EPI, int NPROD>
 hipError_t launch_split_epi(const GemmArgs& a, int tile, hipStream_t s)
 {
     switch (tile) {
+#ifdef ASR_GEMM_ALL_TILES                                                    // development (tools/gemm_split_bench.hip): the tiles that lost
         case 1: return launch_split_tile<4, 1, 4, EPI, NPROD>(a, s);     // 128 x 128
         case 5: return launch_split_tile<5, 1, 4, EPI, NPROD>(a, s);     // 160 x 128
         case 7: return launch_split_tile<2, 2, 4, EPI, NPROD>(a, s);     // 64 x 256, 4 waves of 64 columns
+#endif
         case 9: return launch_split_tile<2, 1, 8, EPI, NPROD>(a, s);     // 64 x 256, 8 waves of 32 columns
         default: return launch_split_tile<2, 1, 4, EPI, NPROD>(a, s);    // 64 x 128
     }
