@@ -7,6 +7,7 @@
 #define ASR_D_HEAD 64          // hidden_units / num_heads of every reference config
 #define ASR_MAX_BEAM 32
 #define ASR_MAX_SPLITK 16
+#define ASR_XATT_SLACK_ROWS 16  // spare rows behind the cross-attention K / V arrays and padding flags (attention.hip reads whole 16-key blocks)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -144,9 +145,9 @@ struct CrossAttnArgs {
     const float* qpart;    // [nsplit][R][hidden] partial q projections
     int nsplit; size_t split_stride;
     const float* qbias;    // [hidden]
-    const float* kc;       // [b][heads][t][64]
-    const float* v;        // [b][heads][t][64]
-    const int32_t* pad2;   // [b][t]
+    const float* kc;       // [b][heads][t][64] + ASR_XATT_SLACK_ROWS rows of 64 floats that may be read (not used)
+    const float* v;        // [b][heads][t][64] + the same slack
+    const int32_t* pad2;   // [b][t] + ASR_XATT_SLACK_ROWS ints of slack
     const int32_t* done;
     float* ctx;            // [R, hidden]
     int b, k, heads, t;

@@ -6,6 +6,7 @@
 // Replaces utils.multihead_attention's core (transformer/utils.py:621-631) and
 // common_attention.dot_product_attention (third_party/tensor2tensor/common_attention.py:295-334).
 #include "asr_common.h"
+#include <type_traits>
 #include <math.h>
 
 namespace {
@@ -370,8 +371,20 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
 // Mask: -1e9 on padded encoder positions exactly as the reference (common_attention.py:202); keys
 // beyond t (block padding) get -inf.
 // ------------------------------------------------------------------------------------------------
+// exp(x) for the soft-max weights (x <= 0 up to rounding) in 6 instructions: x log2(e) is formed in two pieces so that
+// the argument of v_exp_f32 carries no rounding error of its own (the library expf spends twice as many on range checks
+// these arguments never need).  Error ~1.5 ulp; exp(-inf) = 0.
+__device__ __forceinline__ float exp_neg(float x)
+{
+    const float t = x * 1.44269502e+00f;
+    float e = fmaf(x, 1.44269502e+00f, -t);
+    e = fmaf(x, 1.92596303e-08f, e);
+    const float p = __builtin_amdgcn_exp2f(t);
+    return (x == -INFINITY) ? 0.0f : fmaf(p, e * 6.93147182e-01f, p);
+}
+
 template <int NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 4 : 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3 : 2)))
 void decoder_cross_attention_kernel(CrossAttnArgs a)
 {
     if (*a.done) return;
@@ -382,9 +395,13 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
     const int g = lane >> 4, c = lane & 15;
     const int hidden = a.heads * 64, t = a.t, K = a.k;
 
-    const float* kb = a.kc + ((size_t)u * a.heads + h) * t * 64;
-    const float* vb = a.v + ((size_t)u * a.heads + h) * t * 64;
-    const int32_t* padrow = a.pad2 + (size_t)u * t;
+    // K and V of this (utterance, head) are two contiguous [t][64] arrays, so a 16-key block is 4 KB of each and every load
+    // of a block is (per-lane base + block offset) + an immediate: no per-load address arithmetic.  The last block may run
+    // past row t - 1: the engine allocates ASR_XATT_SLACK_ROWS spare rows behind K, V and the padding flags, and those keys
+    // get -inf below.
+    const float* kptr = a.kc + ((size_t)u * a.heads + h) * t * 64 + c * 64 + 4 * g;      // key c, d = 4g .. (+ 16 db)
+    const float* vptr = a.v + ((size_t)u * a.heads + h) * t * 64 + (4 * g) * 64 + 4 * c; // key 4g (+ r), d = 4c ..
+    const int32_t* pptr = a.pad2 + (size_t)u * t + 4 * g;                                 // key 4g (+ r)
     float m_run[NB], l_run[NB];
     f32x4 o[NB][4];
 #pragma unroll
@@ -394,25 +411,73 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
         for (int j = 0; j < 4; ++j) o[nb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    f32x4 qf[NB][4], qb[4];                                     // filled below, after the first block's loads are issued
     const int nblk = (t + 15) >> 4;
-    f32x4 kf[4], vf[4];
-    int32_t padv[4];                                           // branch-free loads: clamped indices, masks applied at use
-    auto load_block = [&](int blk) {
-        const int key0 = blk * 16;
-        const float* kr = kb + (size_t)min(key0 + c, t - 1) * 64 + 4 * g;
+    // two register sets, used alternately (no copies): the next block's loads fly under this block's MFMAs
+    f32x4 kf[2][4], vf[2][4];
+    int32_t padv[2][4];
+    auto load_block = [&](auto setc, int blk) {
+        constexpr int S = decltype(setc)::value;
+        const float* kr = kptr + (size_t)blk * 1024;
+        const float* vr = vptr + (size_t)blk * 1024;
+        const int32_t* pr = pptr + blk * 16;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) kf[db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
+        for (int db = 0; db < 4; ++db) kf[S][db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int key = key0 + 4 * g + r;
-            vf[r] = *reinterpret_cast<const f32x4*>(vb + (size_t)min(key, t - 1) * 64 + 4 * c);
-            padv[r] = padrow[min(key, t - 1)];
+            vf[S][r] = *reinterpret_cast<const f32x4*>(vr + r * 64);
+            padv[S][r] = pr[r];
         }
     };
-    if (wave < nblk) load_block(wave);                       // the first K/V block flies while q is assembled
+    auto compute_block = [&](auto setc, int blk) {
+        constexpr int S = decltype(setc)::value;
+        float bc[4];
+        const int keyq = blk * 16 + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bc[i] = (keyq + i >= t) ? -INFINITY : (padv[S][i] ? -1e9f : 0.0f);
+        if (blk == nblk - 1) {
+            // spare rows past t hold whatever was there (possibly NaN): an -inf score alone would leave 0 x NaN in P.V
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (keyq + i >= t) vf[S][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (blk * 16 + c >= t) {
+#pragma unroll
+                for (int db = 0; db < 4; ++db) kf[S][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[S][db][j], qf[nb][db][j], s, 0, 0, 0);
+            // s[r] = S[beam nb*16+c][key key0 + 4g + r]
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] += bc[r]; mx = fmaxf(mx, s[r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[nb], mx);
+            const float alpha = exp_neg(m_run[nb] - m_new);
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] = exp_neg(s[r] - m_new); ls += s[r]; }
+            l_run[nb] = l_run[nb] * alpha + ls;
+            m_run[nb] = m_new;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[nb][j] = o[nb][j] * alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[S][r][j], s[r], o[nb][j], 0, 0, 0);
+        }
+    };
+    using xc0 = std::integral_constant<int, 0>;
+    using xc1 = std::integral_constant<int, 1>;
+    if (wave < nblk) load_block(xc0{}, wave);                  // the first K/V block flies while q is assembled
 
     // q fragments: split-K slabs fetched two at a time (independent loads in flight), summed in slab order
-    f32x4 qf[NB][4], qb[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) qb[db] = *reinterpret_cast<const f32x4*>(a.qbias + h * 64 + db * 16 + 4 * g);
 #pragma unroll
@@ -446,42 +511,12 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
         }
     }
 
-    for (int blk = wave; blk < nblk; blk += 4) {
-        f32x4 kc4[4], vc4[4];
-        float bc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            kc4[i] = kf[i]; vc4[i] = vf[i];
-            bc[i] = (blk * 16 + 4 * g + i >= t) ? -INFINITY : (padv[i] ? -1e9f : 0.0f);
-        }
-        if (blk + 4 < nblk) load_block(blk + 4);               // next block's loads fly under this block's MFMAs
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc4[db][j], qf[nb][db][j], s, 0, 0, 0);
-            // s[r] = S[beam nb*16+c][key key0 + 4g + r]
-            float mx = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[r] += bc[r]; mx = fmaxf(mx, s[r]); }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[nb], mx);
-            const float alpha = expf(m_run[nb] - m_new);
-            float ls = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[r] = expf(s[r] - m_new); ls += s[r]; }
-            l_run[nb] = l_run[nb] * alpha + ls;
-            m_run[nb] = m_new;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[nb][j] = o[nb][j] * alpha;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc4[r][j], s[r], o[nb][j], 0, 0, 0);
-        }
+    for (int blk = wave; blk < nblk; blk += 8) {
+        if (blk + 4 < nblk) load_block(xc1{}, blk + 4);
+        compute_block(xc0{}, blk);
+        if (blk + 4 >= nblk) break;
+        if (blk + 8 < nblk) load_block(xc0{}, blk + 8);
+        compute_block(xc1{}, blk + 4);
     }
     // o[nb][j][r'] = O[beam nb*16+c][d = 16g + 4r' + j] of this wave's keys (unnormalised)
 #pragma unroll
@@ -502,7 +537,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
             const float M = fmaxf(fmaxf(wm[0][nb][bc], wm[1][nb][bc]), fmaxf(wm[2][nb][bc], wm[3][nb][bc]));
             float sc[4], L = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { sc[w] = expf(wm[w][nb][bc] - M); L += sc[w] * wl[w][nb][bc]; }
+            for (int w = 0; w < 4; ++w) { sc[w] = exp_neg(wm[w][nb][bc] - M); L += sc[w] * wl[w][nb][bc]; }
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -404,11 +404,11 @@ int ensure_encoder_capacity(asr_handle* h, int n, int t)
     rc |= dev_alloc_t(h, &h->qkv, nrows * 3 * H);
     rc |= dev_alloc_t(h, &h->hid, nrows * (size_t)h->F);
     rc |= dev_alloc_t(h, &h->pad, nrows);
-    rc |= dev_alloc_t(h, &h->pad2, nrows);
+    rc |= dev_alloc_t(h, &h->pad2, nrows + ASR_XATT_SLACK_ROWS);
     rc |= dev_alloc_t(h, &h->norm_scratch, input_norm_scratch_doubles(nn, 0, 0));
     for (int l = 0; l < h->L && !rc; ++l) {
-        rc |= dev_alloc_t(h, &h->cross_k[l], nrows * H);
-        rc |= dev_alloc_t(h, &h->cross_v[l], nrows * H);
+        rc |= dev_alloc_t(h, &h->cross_k[l], nrows * H + ASR_XATT_SLACK_ROWS * 64);
+        rc |= dev_alloc_t(h, &h->cross_v[l], nrows * H + ASR_XATT_SLACK_ROWS * 64);
     }
     if (rc) return ASR_ERR_HIP;
     h->cap_rows = nrows; h->cap_n = nn;

@@ -19,13 +19,13 @@ int main(int argc, char** argv)
     srand(1);
     for (auto& x : h) x = rand() / (float)RAND_MAX - 0.5f;
     for (int l = 0; l < L; ++l) {
-        CK(hipMalloc(&kc[l], kvn * 4)); CK(hipMalloc(&vc[l], kvn * 4));
+        CK(hipMalloc(&kc[l], kvn * 4 + ASR_XATT_SLACK_ROWS * 256)); CK(hipMalloc(&vc[l], kvn * 4 + ASR_XATT_SLACK_ROWS * 256));
         CK(hipMemcpy(kc[l], h.data(), kvn * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(vc[l], h.data(), kvn * 4, hipMemcpyHostToDevice));
     }
     float *q, *qb, *ctx; int32_t *pad, *done;
     CK(hipMalloc(&q, (size_t)2 * R * H * 4)); CK(hipMalloc(&qb, H * 4)); CK(hipMalloc(&ctx, (size_t)R * H * 4));
-    CK(hipMalloc(&pad, (size_t)B * T * 4)); CK(hipMalloc(&done, 4));
+    CK(hipMalloc(&pad, (size_t)B * T * 4 + ASR_XATT_SLACK_ROWS * 4)); CK(hipMalloc(&done, 4));
     CK(hipMemcpy(q, h.data(), (size_t)2 * R * H * 4, hipMemcpyHostToDevice));
     CK(hipMemset(qb, 0, H * 4)); CK(hipMemset(pad, 0, (size_t)B * T * 4)); CK(hipMemset(done, 0, 4));
     hipStream_t st; CK(hipStreamCreate(&st));
