@@ -155,6 +155,18 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(MhaArgs a)
     }
 }
 
+// exp(x) for the soft-max weights (x <= 0 up to rounding) in 6 instructions: x log2(e) is formed in two pieces so that
+// the argument of v_exp_f32 carries no rounding error of its own (the library expf spends twice as many on range checks
+// these arguments never need).  Error ~1.5 ulp; exp(-inf) = 0.
+__device__ __forceinline__ float exp_neg(float x)
+{
+    const float t = x * 1.44269502e+00f;
+    float e = fmaf(x, 1.44269502e+00f, -t);
+    e = fmaf(x, 1.92596303e-08f, e);
+    const float p = __builtin_amdgcn_exp2f(t);
+    return (x == -INFINITY) ? 0.0f : fmaf(p, e * 6.93147182e-01f, p);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Decoder self-attention at position `pos` (model.py:588-600 with reserve_last; no mask).
 // One workgroup per (utterance, head) serves all beams.  The beams' own k/v of position `pos` are
@@ -261,10 +273,10 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run[nb], mx);
             const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;     // beam without a key so far: all weights 0
-            const float alpha = expf(m_run[nb] - m_use);
+            const float alpha = exp_neg(m_run[nb] - m_use);
             float lsum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[r] = expf(s[r] - m_use); lsum += s[r]; }
+            for (int r = 0; r < 4; ++r) { s[r] = exp_neg(s[r] - m_use); lsum += s[r]; }
             l_run[nb] = l_run[nb] * alpha + lsum;
             m_run[nb] = m_new;
 #pragma unroll
@@ -280,31 +292,34 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
     // (clamped list index) and run one block ahead of the MFMAs
     const int nblk = (n_live + 15) >> 4;
     const size_t head_base = ((size_t)u * a.heads + h) * width;   // rows of this (utterance, head): [position][slot][64]
-    f32x4 kf[4], vf[4];
-    int ej[4], es[4];
-    auto load_block = [&](int blk) {
+    // two register sets, used alternately (no copies): the next block's loads fly under this block's MFMAs
+    f32x4 kf[2][4], vf[2][4];
+    int ej[2][4], es[2][4];
+    auto load_block = [&](auto setc, int blk) {
+        constexpr int S = decltype(setc)::value;
         const int key0 = blk * 16;
         const int e = live[min(key0 + c, n_live - 1)];
         const float* kr = a.kcache + ((head_base + (e >> 5)) * K + (e & 31)) * 64 + 4 * g;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) kf[db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
+        for (int db = 0; db < 4; ++db) kf[S][db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = key0 + 4 * g + r;
             const int er = live[min(idx, n_live - 1)];
-            vf[r] = *reinterpret_cast<const f32x4*>(a.vcache + ((head_base + (er >> 5)) * K + (er & 31)) * 64 + 4 * c);
-            ej[r] = er >> 5;
-            es[r] = idx < n_live ? (er & 31) : -2;
+            vf[S][r] = *reinterpret_cast<const f32x4*>(a.vcache + ((head_base + (er >> 5)) * K + (er & 31)) * 64 + 4 * c);
+            ej[S][r] = er >> 5;
+            es[S][r] = idx < n_live ? (er & 31) : -2;
         }
     };
-    if (wave < nblk) load_block(wave);
-    for (int blk = wave; blk < nblk; blk += 4) {
-        f32x4 kc4[4], vc4[4];
-        int cj[4], cs[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { kc4[i] = kf[i]; vc4[i] = vf[i]; cj[i] = ej[i]; cs[i] = es[i]; }
-        if (blk + 4 < nblk) load_block(blk + 4);
-        compute(kc4, vc4, cj, cs);
+    using sc0 = std::integral_constant<int, 0>;
+    using sc1 = std::integral_constant<int, 1>;
+    if (wave < nblk) load_block(sc0{}, wave);
+    for (int blk = wave; blk < nblk; blk += 8) {
+        if (blk + 4 < nblk) load_block(sc1{}, blk + 4);
+        compute(kf[0], vf[0], ej[0], es[0]);
+        if (blk + 4 >= nblk) break;
+        if (blk + 8 < nblk) load_block(sc0{}, blk + 8);
+        compute(kf[1], vf[1], ej[1], es[1]);
     }
     // ---- the new position: key = beam, from LDS
 #pragma unroll
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
             const float M = fmaxf(fmaxf(wm[0][nb][bc], wm[1][nb][bc]), fmaxf(wm[2][nb][bc], wm[3][nb][bc]));
             float sc[4], L = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { sc[w] = expf(wm[w][nb][bc] - M); L += sc[w] * wl[w][nb][bc]; }
+            for (int w = 0; w < 4; ++w) { sc[w] = exp_neg(wm[w][nb][bc] - M); L += sc[w] * wl[w][nb][bc]; }
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -371,18 +386,6 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
 // Mask: -1e9 on padded encoder positions exactly as the reference (common_attention.py:202); keys
 // beyond t (block padding) get -inf.
 // ------------------------------------------------------------------------------------------------
-// exp(x) for the soft-max weights (x <= 0 up to rounding) in 6 instructions: x log2(e) is formed in two pieces so that
-// the argument of v_exp_f32 carries no rounding error of its own (the library expf spends twice as many on range checks
-// these arguments never need).  Error ~1.5 ulp; exp(-inf) = 0.
-__device__ __forceinline__ float exp_neg(float x)
-{
-    const float t = x * 1.44269502e+00f;
-    float e = fmaf(x, 1.44269502e+00f, -t);
-    e = fmaf(x, 1.92596303e-08f, e);
-    const float p = __builtin_amdgcn_exp2f(t);
-    return (x == -INFINITY) ? 0.0f : fmaf(p, e * 6.93147182e-01f, p);
-}
-
 template <int NB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3 : 2)))
 void decoder_cross_attention_kernel(CrossAttnArgs a)
