@@ -301,12 +301,12 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
         const int e = live[min(key0 + c, n_live - 1)];
         const float* kr = a.kcache + ((head_base + (e >> 5)) * K + (e & 31)) * 64 + 4 * g;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) kf[S][db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
+        for (int db = 0; db < 4; ++db) kf[S][db] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kr + db * 16));   // streamed once per step
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = key0 + 4 * g + r;
             const int er = live[min(idx, n_live - 1)];
-            vf[S][r] = *reinterpret_cast<const f32x4*>(a.vcache + ((head_base + (er >> 5)) * K + (er & 31)) * 64 + 4 * c);
+            vf[S][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.vcache + ((head_base + (er >> 5)) * K + (er & 31)) * 64 + 4 * c));
             ej[S][r] = er >> 5;
             es[S][r] = idx < n_live ? (er & 31) : -2;
         }
@@ -425,10 +425,10 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
         const float* vr = vptr + (size_t)blk * 1024;
         const int32_t* pr = pptr + blk * 16;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) kf[S][db] = *reinterpret_cast<const f32x4*>(kr + db * 16);
+        for (int db = 0; db < 4; ++db) kf[S][db] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kr + db * 16));   // streamed once: keep it out of the caches
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            vf[S][r] = *reinterpret_cast<const f32x4*>(vr + r * 64);
+            vf[S][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vr + r * 64));
             padv[S][r] = pr[r];
         }
     };
