@@ -446,15 +446,16 @@ __global__ __launch_bounds__(256) void log_softmax_topk_kernel(const float* __re
 
 // Same result for rows of at most 1024*NV elements, held in REGISTERS (thread t owns the 16-byte groups t, t+256, ...):
 // no LDS image of the row, 16-byte loads of the slabs, and the arg-max rounds rescan registers.
-template <int NV>
-__global__ __launch_bounds__(256) void log_softmax_topk_reg_kernel(const float* __restrict__ logits, int nsplit, size_t split_stride,
+template <int NV, int NW>   // NW waves per row (4 or 16): thread t owns the 16-byte groups t, t + 64 NW, ...
+__global__ __launch_bounds__(64 * NW) void log_softmax_topk_reg_kernel(const float* __restrict__ logits, int nsplit, size_t split_stride,
                                                                     int vocab, int k, float* __restrict__ values,
                                                                     int32_t* __restrict__ indices, const int32_t* __restrict__ done)
 {
     if (done && *done) return;
-    __shared__ float redv[2][4];
-    __shared__ float candv[4 * ASR_MAX_BEAM];
-    __shared__ int candi[4 * ASR_MAX_BEAM];
+    constexpr int NT = 64 * NW;
+    __shared__ float redv[2][NW];
+    __shared__ float candv[NW * ASR_MAX_BEAM];
+    __shared__ int candi[NW * ASR_MAX_BEAM];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const f32x4* x = reinterpret_cast<const f32x4*>(logits + (size_t)r * vocab);
     const size_t stride4 = split_stride / 4;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void log_softmax_topk_reg_kernel(const float* 
     float v[NV * 4];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int g = tid + 256 * j;
+        const int g = tid + NT * j;
         const bool ok = g < groups;
         const int gc = ok ? g : 0;                                   // branch-free, clamped address
         f32x4 a = x[gc];
@@ -479,22 +480,52 @@ __global__ __launch_bounds__(256) void log_softmax_topk_reg_kernel(const float* 
     m = wave_max(m);
     if (lane == 0) redv[0][wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(redv[0][0], redv[0][1]), fmaxf(redv[0][2], redv[0][3]));
+    m = redv[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, redv[0][w]);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < NV * 4; ++e) { v[e] -= m; s += expf(v[e]); }   // exp(-inf) = 0 for the slots past the row
     s = wave_sum(s);
     if (lane == 0) redv[1][wave] = s;
     __syncthreads();
-    const float logz = logf((redv[1][0] + redv[1][1]) + (redv[1][2] + redv[1][3]));
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
+    float zsum = 0.f;                                                // pairs of pairs, in wave order (NW = 4: (s0 + s1) + (s2 + s3))
 #pragma unroll
-    for (int e = 0; e < NV * 4; ++e) {
-        v[e] -= logz;
-        const int idx = 4 * (tid + 256 * (e >> 2)) + (e & 3);
-        if (v[e] > bv) { bv = v[e]; bi = idx; }                     // ascending index order: the first maximum is kept
+    for (int w = 0; w < NW; w += 4) {
+        const float q4 = (redv[1][w] + redv[1][w + 1]) + (redv[1][w + 2] + redv[1][w + 3]);
+        zsum = (w == 0) ? q4 : zsum + q4;
     }
+    const float logz = logf(zsum);
+    // The lane's elements are kept in groups of 16 with the best of every group cached, so that after one of them has been
+    // taken only its group is rescanned (a 28444-word row is 112 elements per lane: rescanning them all cost 190 us a step).
+    // Ascending element order = ascending index, strict comparisons: the first maximum is kept everywhere.
+    constexpr int NE = NV * 4, GS = NE < 16 ? NE : 16, NG = NE / GS;
+    float gv[NG];
+    int gi[NG];
+    auto idx_of = [&](int e) { return 4 * (tid + NT * (e >> 2)) + (e & 3); };
+    auto scan_group = [&](int g) {
+        float bvg = -INFINITY;
+        int big = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            const int e = g * GS + j;
+            if (v[e] > bvg) { bvg = v[e]; big = idx_of(e); }
+        }
+        gv[g] = bvg; gi[g] = big;
+    };
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] -= logz;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) scan_group(g);
+    float bv;
+    int bi;
+    auto best_of_groups = [&]() {
+        bv = -INFINITY; bi = 0x7fffffff;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            if (gv[g] > bv) { bv = gv[g]; bi = gi[g]; }
+    };
+    best_of_groups();
     for (int round = 0; round < k; ++round) {
         float wv = bv;
         int wi = bi;
@@ -505,20 +536,23 @@ __global__ __launch_bounds__(256) void log_softmax_topk_reg_kernel(const float* 
             if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
         }
         if (lane == 0) { candv[wave * k + round] = wv; candi[wave * k + round] = wi; }
-        if (wi == bi && bi != 0x7fffffff) {                         // this lane owned the winner: retire it, rescan
+        if (wi == bi && bi != 0x7fffffff) {                         // this lane owned the winner: retire it, rescan its group
             const int taken = bi;
-            bv = -INFINITY; bi = 0x7fffffff;
+            const int esel = (((taken >> 2) - tid) / NT) * 4 + (taken & 3);
 #pragma unroll
-            for (int e = 0; e < NV * 4; ++e) {
-                const int idx = 4 * (tid + 256 * (e >> 2)) + (e & 3);
-                if (idx == taken) v[e] = -INFINITY;
-                if (v[e] > bv) { bv = v[e]; bi = idx; }
-            }
+            for (int g = 0; g < NG; ++g)
+                if (esel / GS == g) {
+#pragma unroll
+                    for (int j = 0; j < GS; ++j)
+                        if (idx_of(g * GS + j) == taken) v[g * GS + j] = -INFINITY;
+                    scan_group(g);
+                }
+            best_of_groups();
         }
     }
     if (tid < k) { values[(size_t)r * k + tid] = -INFINITY; indices[(size_t)r * k + tid] = 0; }   // ranks no candidate reaches
     __syncthreads();
-    const int nc = 4 * k;
+    const int nc = NW * k;
     if (tid < nc) {
         const float cv = candv[tid];
         const int idx = candi[tid];
@@ -777,13 +811,18 @@ hipError_t launch_log_softmax_topk(const float* logits, int nsplit, size_t split
     if (rows <= 0) return hipSuccess;
     const size_t lds = (size_t)vocab * sizeof(float);
     if (lds > 150 * 1024 || k < 1 || k > vocab || k > ASR_MAX_BEAM || nsplit < 1) return hipErrorInvalidValue;
-    if ((vocab & 3) == 0 && (split_stride & 3) == 0 && vocab <= 4096 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
-        if (vocab <= 2048)
-            hipLaunchKernelGGL(log_softmax_topk_reg_kernel<2>, dim3(rows), dim3(256), 0, s, logits, nsplit, split_stride, vocab, k,
-                               values, indices, done);
-        else
-            hipLaunchKernelGGL(log_softmax_topk_reg_kernel<4>, dim3(rows), dim3(256), 0, s, logits, nsplit, split_stride, vocab, k,
-                               values, indices, done);
+    // rows of up to 32768 elements live in registers (16-byte slab loads, no LDS image); the LDS variant (one 4-byte load
+    // per element, one workgroup per CU, arg-max rescans through LDS) took 368 us per step at the word vocabulary (28444)
+    // against 18 us at 3900
+    if ((vocab & 3) == 0 && (split_stride & 3) == 0 && vocab <= 32768 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+#define TOPK_REG(NV, NW) hipLaunchKernelGGL((log_softmax_topk_reg_kernel<NV, NW>), dim3(rows), dim3(64 * NW), 0, s, logits, nsplit, \
+                                            split_stride, vocab, k, values, indices, done)
+        if (vocab <= 2048) TOPK_REG(2, 4);
+        else if (vocab <= 4096) TOPK_REG(4, 4);
+        else if (vocab <= 8192) TOPK_REG(2, 16);          // long rows: 1024 threads a row keep the per-thread chains short
+        else if (vocab <= 16384) TOPK_REG(4, 16);
+        else TOPK_REG(8, 16);
+#undef TOPK_REG
         return hipGetLastError();
     }
     static bool attr_done[64] = {};

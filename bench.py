@@ -41,10 +41,10 @@ PRECISION_INFO = {
 }
 
 
-def bench_config(beam=10, mtl=200, precision='f32_f16x3'):
+def bench_config(beam=10, mtl=200, precision='f32_f16x3', vocab=3900):
     from asr_amd.utils import AttrDict
     return AttrDict({
-        'model': 'Transformer', 'dst_vocab_size': 3900, 'hidden_units': 1024, 'scale_embedding': True,
+        'model': 'Transformer', 'dst_vocab_size': vocab, 'hidden_units': 1024, 'scale_embedding': True,
         'tie_embedding_and_softmax': True, 'num_blocks': 6, 'num_heads': 16, 'ff_activation': 'glu',
         'train': {'input_dim': 320},
         'test': {'batch_size': 64, 'max_target_length': mtl, 'lp_alpha': 0.6, 'beam_size': beam, 'num_gpus': 1,
@@ -106,6 +106,8 @@ def main():
     ap.add_argument('--t-raw', type=int, default=1000)
     ap.add_argument('--beam', type=int, default=10)
     ap.add_argument('--max-target-length', type=int, default=200)
+    ap.add_argument('--vocab', type=int, default=3900, help='dst_vocab_size: 3900 = char config (the headline), 1388 = pinyin, '
+                    '28444 = word, 3205 = SEAME')
     ap.add_argument('--cpu-sample-utts', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_f16x3'), choices=sorted(PRECISION_INFO))
@@ -133,7 +135,7 @@ def main():
         else:
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
-    cfg = bench_config(args.beam, args.max_target_length, args.precision)
+    cfg = bench_config(args.beam, args.max_target_length, args.precision, args.vocab)
     W = weights.random_init(cfg, seed=0)
     eng = Engine(cfg, local_rank)
     eng.load_weights(W)
@@ -183,10 +185,12 @@ def main():
             'value': audio_s / elapsed, 'unit': 'audio-sec/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / max(args.steps, 1), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': PRECISION_INFO[args.precision][0], 'data': 'synthetic',
-            'config': {'workload': 'char config (hidden 1024, 16 heads, 6+6 blocks, GLU 4096, tied V=3900), beam %d, '
+            'config': {'workload': '%s (hidden 1024, 16 heads, 6+6 blocks, GLU 4096, tied V=%d), beam %d, '
                                    'max_target_length %d, %d x %.0f s synthetic fbank utterances per GPU per step '
                                    '(T=%d stacked frames), random-init weights, %d decode steps taken'
-                                   % (args.beam, args.max_target_length, n, t_raw / 100.0, (t_raw + 2) // 3, Y.shape[1]),
+                                   % ('char config' if args.vocab == 3900 else 'char architecture with another vocabulary',
+                                      args.vocab, args.beam, args.max_target_length, n, t_raw / 100.0, (t_raw + 2) // 3,
+                                      Y.shape[1]),
                        'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world, 'precision': args.precision,
                        # precision f32_f16x3: calls the library repeated on the bf16x6 kernels because an operand left
                        # fp16's range (0 = every timed step ran on the fp16x3 kernels)
