@@ -28,38 +28,44 @@ from .utils import shard_bounds
 DEFAULT_PRECISION = 'f32_f16x3'
 
 
+def asr_config_from(config, device=0):
+    """YAML config (AttrDict; the keys model.py:19-45,434-442 read) -> (`asr_config` struct of include/asr_amd.h,
+    precision name).  Pure host code: no library call, so CPU tests can check what every reference YAML derives."""
+    t = config.test
+    c = _lib.asr_config()
+    c.input_dim = int(config.train.input_dim)
+    c.hidden_units = int(config.hidden_units)
+    c.num_heads = int(config.num_heads)
+    c.num_blocks = int(config.num_blocks)
+    c.dst_vocab_size = int(config.dst_vocab_size)
+    act = config.ff_activation or 'relu'
+    if act not in _lib.FF_ACTIVATIONS:
+        raise ValueError('unknown ff_activation %r' % act)
+    c.ff_activation = _lib.FF_ACTIVATIONS[act]
+    c.scale_embedding = 1 if config.scale_embedding else 0
+    c.tie_embedding_and_softmax = 1 if config.tie_embedding_and_softmax else 0
+    c.beam_size = int(t.beam_size)
+    c.max_target_length = int(t.max_target_length)
+    c.lp_alpha = float(t.lp_alpha)
+    c.device = int(device)
+    # build extension (not a reference key): arithmetic of the dense layers, see include/asr_amd.h asr_precision
+    prec = (t.precision if t.precision is not None else os.environ.get('ASR_AMD_PRECISION')) or DEFAULT_PRECISION
+    if prec not in _lib.PRECISIONS:
+        raise ValueError('unknown test.precision %r (one of %s)' % (prec, sorted(_lib.PRECISIONS)))
+    c.precision = _lib.PRECISIONS[prec]
+    # build extension: 1 = one run of kernels per batch, 2 = two independent halves on two streams, None = library default
+    sb = int(t.sub_batches or 0)
+    if sb not in (0, 1, 2):
+        raise ValueError('test.sub_batches must be 1 or 2')
+    c.sub_batches = sb
+    return c, prec
+
+
 class Engine(object):
     """One libasr_amd handle = one GPU's weights, K/V caches and workspaces."""
 
     def __init__(self, config, device=0):
-        t = config.test
-        c = _lib.asr_config()
-        c.input_dim = int(config.train.input_dim)
-        c.hidden_units = int(config.hidden_units)
-        c.num_heads = int(config.num_heads)
-        c.num_blocks = int(config.num_blocks)
-        c.dst_vocab_size = int(config.dst_vocab_size)
-        act = config.ff_activation or 'relu'
-        if act not in _lib.FF_ACTIVATIONS:
-            raise ValueError('unknown ff_activation %r' % act)
-        c.ff_activation = _lib.FF_ACTIVATIONS[act]
-        c.scale_embedding = 1 if config.scale_embedding else 0
-        c.tie_embedding_and_softmax = 1 if config.tie_embedding_and_softmax else 0
-        c.beam_size = int(t.beam_size)
-        c.max_target_length = int(t.max_target_length)
-        c.lp_alpha = float(t.lp_alpha)
-        c.device = int(device)
-        # build extension (not a reference key): arithmetic of the dense layers, see include/asr_amd.h asr_precision
-        prec = (t.precision if t.precision is not None else os.environ.get('ASR_AMD_PRECISION')) or DEFAULT_PRECISION
-        if prec not in _lib.PRECISIONS:
-            raise ValueError('unknown test.precision %r (one of %s)' % (prec, sorted(_lib.PRECISIONS)))
-        c.precision = _lib.PRECISIONS[prec]
-        self.precision = prec
-        # build extension: 1 = one run of kernels per batch, 2 = two independent halves on two streams, None = library default
-        sb = int(t.sub_batches or 0)
-        if sb not in (0, 1, 2):
-            raise ValueError('test.sub_batches must be 1 or 2')
-        c.sub_batches = sb
+        c, self.precision = asr_config_from(config, device)
         self.cfg = c
         self.device = int(device)
         self._h = C.c_void_p()
