@@ -37,6 +37,19 @@ def tiny_inputs(lens=(60, 90, 75), seed=2):
 
 
 def rel_err(a, b):
+    """How the tests read north_star's "logits within 1e-3 relative error": the largest absolute difference over the
+    WHOLE tensor divided by the largest magnitude of the reference tensor (a per-element ratio is meaningless where a
+    logit passes through zero).  rel_err_rows below is the stricter per-row (per-hypothesis) form."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def rel_err_rows(a, b):
+    """Per-row variant: max over rows (last axis = one logit vector) of max|a - b| / max|b| of that row."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    a = a.reshape(-1, a.shape[-1])
+    b = b.reshape(-1, b.shape[-1])
+    den = np.maximum(np.max(np.abs(b), axis=1), 1e-30)
+    return float(np.max(np.max(np.abs(a - b), axis=1) / den))
