@@ -17,6 +17,18 @@ namespace {
 
 std::string g_create_error;
 
+// ---- scratch of the allocation-free entry point (asr_op_input_norm_timing_noalloc) ----------------------------
+// The per-utterance partial sums of the input layer norm (rowops.hip: 2 x 64 doubles per utterance) live in this
+// file-scope device array instead of a hipMalloc'ed buffer.  In host code the array's NAME is only a stand-in (passing
+// it to a kernel compiles and then faults the GPU): asr_create resolves its device address once per device, with that
+// device current, by hipGetSymbolAddress, and host code uses that pointer everywhere.  Every GPU the library runs on
+// holds its own 1 MiB copy until the process ends.
+constexpr int NOALLOC_MAX_UTTS = 1024;
+constexpr int NOALLOC_DOUBLES_PER_UTT = 128;
+constexpr int MAX_DEVICES = 64;
+static __device__ __align__(256) double g_norm_scratch[NOALLOC_MAX_UTTS * NOALLOC_DOUBLES_PER_UTT];
+double* g_norm_scratch_ptr[MAX_DEVICES] = {};      // device address of g_norm_scratch on device d (null: not resolved yet)
+
 struct HostTensor {
     std::vector<float> data;
     std::vector<int64_t> shape;
@@ -934,7 +946,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
         if (cfg->reserved[i]) return bad("reserved fields must be zero");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device visible (libasr_amd needs an MI355X)"; return ASR_ERR_HIP; }
-    if (cfg->device < 0 || cfg->device >= ndev) return bad("device ordinal out of range");
+    if (cfg->device < 0 || cfg->device >= ndev || cfg->device >= MAX_DEVICES) return bad("device ordinal out of range");
 
     asr_handle* h = new asr_handle();
     h->cfg = *cfg;
@@ -957,6 +969,13 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     };
     hipError_t e;
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if (!g_norm_scratch_ptr[cfg->device]) {                 // once per device, with that device current
+        double* p = nullptr;
+        if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_norm_scratch))) != hipSuccess)
+            return hip_fail(e, "hipGetSymbolAddress(g_norm_scratch)");
+        if (!p) return hip_fail(hipErrorInvalidSymbol, "hipGetSymbolAddress(g_norm_scratch)");
+        g_norm_scratch_ptr[cfg->device] = p;
+    }
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->range_flag), 16)) != hipSuccess) return hip_fail(e, "hipMalloc");
     if ((e = hipMemset(h->range_flag, 0, 16)) != hipSuccess) return hip_fail(e, "hipMemset");
@@ -973,6 +992,12 @@ int asr_create(const asr_config* cfg, asr_handle** out)
         return hip_fail(e, "hipHostMalloc");
     h->cross_k.assign(h->L, nullptr); h->cross_v.assign(h->L, nullptr);
     h->kcache.assign(h->L, nullptr); h->vcache.assign(h->L, nullptr);
+    // the timing-signal table exists from here on (the allocation-free entry point cannot build or grow it)
+    if (ensure_pe(h, cfg->max_target_length + 2) != ASR_OK) {
+        g_create_error = "timing table: " + h->err;
+        asr_destroy(h);
+        return ASR_ERR_HIP;
+    }
     *out = h;
     return ASR_OK;
 }
@@ -1462,6 +1487,48 @@ int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, 
     HIP_TRY(h, launch_input_norm_timing(dx, dg, db, h->pe, n, t, hidden, dscr, dy, s));
     HIP_TRY(h, hipMemcpyAsync(y, dy, cnt * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
+// Allocation-free variant of asr_op_input_norm_timing (include/asr_amd.h): inputs and output are DEVICE pointers of this
+// handle's GPU, the partial-sum scratch is the file-scope g_norm_scratch array (through the pointer asr_create resolved),
+// the timing table is the one the handle already holds.  No hipMalloc / hipFree / allocating call on any path.
+int asr_op_input_norm_timing_noalloc(asr_handle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev, int32_t n, int32_t t,
+                                     int32_t hidden, float* y_dev)
+{
+    if (!h) return ASR_ERR_ARG;
+    if (!x_dev || !gamma_dev || !beta_dev || !y_dev || n < 1 || t < 1 || hidden != h->H)
+        return fail(h, ASR_ERR_ARG, "bad argument (hidden must equal the handle's hidden_units)");
+    if (n > NOALLOC_MAX_UTTS)
+        return fail(h, ASR_ERR_CAPACITY, "asr_op_input_norm_timing_noalloc: n = " + std::to_string(n) + " exceeds the static scratch (" +
+                                             std::to_string(NOALLOC_MAX_UTTS) + " utterances per call)");
+    if (t > h->pe_rows)
+        return fail(h, ASR_ERR_CAPACITY, "asr_op_input_norm_timing_noalloc: t = " + std::to_string(t) + " exceeds the handle's timing table (" +
+                                             std::to_string(h->pe_rows) + " positions; this entry point cannot grow it)");
+    if ((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(gamma_dev) | reinterpret_cast<uintptr_t>(beta_dev) |
+         reinterpret_cast<uintptr_t>(y_dev)) & 15)
+        return fail(h, ASR_ERR_ARG, "device pointers must be 16-byte aligned");
+    int rc = set_device(h);
+    if (rc) return rc;
+    // a host pointer here would fault the GPU: every pointer must be device memory of this handle's device
+    const void* ptrs[4] = {x_dev, gamma_dev, beta_dev, y_dev};
+    for (const void* q : ptrs) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, q) != hipSuccess || (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) ||
+            (at.type == hipMemoryTypeDevice && at.device != h->cfg.device)) {
+            (void)hipGetLastError();
+            return fail(h, ASR_ERR_ARG, "asr_op_input_norm_timing_noalloc takes device pointers of the handle's GPU");
+        }
+    }
+    double* scratch = g_norm_scratch_ptr[h->cfg.device];
+    if (!scratch) return fail(h, ASR_ERR_STATE, "static scratch was not resolved on this device");
+    static_assert(NOALLOC_DOUBLES_PER_UTT == 128, "rowops.hip: 2 x 64 partial sums per utterance");
+    if (input_norm_scratch_doubles(n, t, hidden) > (size_t)NOALLOC_MAX_UTTS * NOALLOC_DOUBLES_PER_UTT)
+        return fail(h, ASR_ERR_CAPACITY, "static scratch too small");
+    // Nothing in the scratch has to start at zero: the first statistics kernel writes every slot the later ones read
+    // (rowops.hip input_norm_stats_kernel), so the previous call's contents are simply overwritten.
+    HIP_TRY(h, launch_input_norm_timing(x_dev, gamma_dev, beta_dev, h->pe, n, t, hidden, scratch, y_dev, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return ASR_OK;
 }
 

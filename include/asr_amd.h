@@ -174,6 +174,18 @@ int asr_op_add_layer_norm(asr_handle* h, const float* x, const float* delta, con
  * (model.py:453,456): x [n,t,hidden] -> y. */
 int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, const float* beta,
                              int32_t n, int32_t t, int32_t hidden, float* y);
+/* Allocation-free variant of asr_op_input_norm_timing.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * x_dev / gamma_dev / beta_dev / y_dev are DEVICE pointers on the handle's GPU, 16-byte aligned (x, y [n,t,hidden];
+ * gamma, beta [hidden]); the per-utterance partial sums that the other entry point keeps in a hipMalloc'ed buffer live
+ * in a static device array of the library (1 MiB per GPU, held until the process ends).  Calls no hipMalloc / hipFree
+ * and no allocating routine.  Limits: n <= 1024 utterances per call and t <= the positions of the handle's timing
+ * table (max(512, max_target_length + 2), or more once another entry point has grown it); beyond either the call
+ * fails with ASR_ERR_CAPACITY and touches nothing.  All calls on one GPU share that GPU's array (the last call's
+ * contents are overwritten, nothing needs clearing): calls that OVERLAP on one GPU - two handles of one device used
+ * from two threads - race.  Blocks until y_dev is valid.  Results are bit-identical to asr_op_input_norm_timing. */
+int asr_op_input_norm_timing_noalloc(asr_handle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                                     int32_t n, int32_t t, int32_t hidden, float* y_dev);
 /* Encoder self-attention core (utils.py:624-631; common_attention.py:295-334): qkv [n,t,3*hidden]
  * (q | k | v, q NOT yet scaled), pad [n,t] int32 -> ctx [n,t,hidden]. */
 int asr_op_encoder_attention(asr_handle* h, const float* qkv, const int32_t* pad,
