@@ -11,6 +11,20 @@ max_target_length 200, 64 synthetic 10-second utterances per GPU per step.
 One process per GPU; every rank decodes its own 64-utterance batch (weak scaling, utterances are
 independent), then the hypotheses are gathered with one RCCL all_gather of a fixed-width int32
 buffer (the path's only exchange, model.py:192-201).  Rank 0 prints ONE JSON line.
+
+The same line also carries, at N = 1 (all timed by this run, on this box):
+  roofline            dominant kernel class, HIP events around every launch of one extra pass that launches the same
+                      shapes as the timed passes (same half batches)
+  cpu_baseline        the oracle's K/V-cache decode on a few utterances (the formulation most favourable to the CPU)
+  cpu_baseline_ref_shaped   the oracle's LITERAL reference algorithm (model.py:559-633: block-output cache, K/V of the
+                      history and of the beam-tiled encoder re-projected every step) on 1 utterance for 20 steps,
+                      with the extrapolation to 201 steps by the algorithm's FLOP count stated
+  alt_precisions      the other dense-layer arithmetics (f32_bf16x6, f32, bf16), a few steps each, with a flag saying
+                      whether their hypotheses equal the headline mode's
+
+`--workload bucketed` instead runs BASELINE configs 3/4 as stated: ragged utterances, 10-frame length buckets
+(utils.py:285-323), batches dealt over the ranks by cost, each rank decoding its share with the real engine, one
+all_gather of the hypotheses; a step = the whole utterance set.
 """
 from __future__ import annotations
 
@@ -39,6 +53,7 @@ PRECISION_INFO = {
     'bf16x3': ('bf16x3 (2-term bf16 split, 3 MFMA products, f32 accumulate)', 3, PEAK_BF16_MFMA_TFLOPS),
     'bf16': ('bf16 (f32 accumulate; attention, layer norms and beam search in f32)', 1, PEAK_BF16_MFMA_TFLOPS),
 }
+MFMA_KERNELS = ('gemm', 'encoder_attention')          # classes priced against the matrix pipe; everything else against HBM
 
 
 def bench_config(beam=10, mtl=200, precision='f32_f16x3', vocab=3900):
@@ -54,7 +69,8 @@ def bench_config(beam=10, mtl=200, precision='f32_f16x3', vocab=3900):
 
 def measured_traffic(kernel_class, precision):
     """HBM-side bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    collected and corrected by tools/pmc_traffic.py on this same command); None when that class was not profiled."""
+    collected and corrected by tools/pmc_traffic.py on this same command); None when that class was not profiled.
+    Later files (sorted by name: r02 after r01) win."""
     best = None
     pdir = os.path.join(ROOT, 'profiles')
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -71,30 +87,201 @@ def synthetic_raw(n, t_raw, seed):
     return rng.standard_normal((n, t_raw, 80)).astype(np.float32)
 
 
+def _oracle_config(cfg, mtl=None):
+    from oracle import asr_oracle as O
+    return O.make_config(hidden_units=cfg.hidden_units, num_heads=cfg.num_heads, num_blocks=cfg.num_blocks,
+                         dst_vocab_size=cfg.dst_vocab_size, input_dim=cfg.train.input_dim,
+                         ff_activation=cfg.ff_activation, scale_embedding=cfg.scale_embedding,
+                         tie_embedding_and_softmax=cfg.tie_embedding_and_softmax, beam_size=cfg.test.beam_size,
+                         max_target_length=cfg.test.max_target_length if mtl is None else mtl, lp_alpha=cfg.test.lp_alpha)
+
+
+def _blas_threads():
+    try:
+        import threadpoolctl
+        info = threadpoolctl.threadpool_info()
+        return int(max([i.get('num_threads', 1) for i in info] or [1]))
+    except Exception:
+        return int(os.environ.get('OMP_NUM_THREADS', '1'))
+
+
 def cpu_baseline(cfg, W, raw, sample_utts):
     """The oracle (CPU restatement of the reference algorithm, K/V-cache formulation: the variant most
     favourable to the CPU) timed on this box's host cores over a bounded sample of the same workload."""
     from oracle import asr_oracle as O
-    try:
-        import threadpoolctl
-        info = threadpoolctl.threadpool_info()
-        cores = max([i.get('num_threads', 1) for i in info] or [1])
-    except Exception:
-        cores = int(os.environ.get('OMP_NUM_THREADS', '1'))
-    ocfg = O.make_config(hidden_units=cfg.hidden_units, num_heads=cfg.num_heads, num_blocks=cfg.num_blocks,
-                         dst_vocab_size=cfg.dst_vocab_size, input_dim=cfg.train.input_dim,
-                         ff_activation=cfg.ff_activation, scale_embedding=cfg.scale_embedding,
-                         tie_embedding_and_softmax=cfg.tie_embedding_and_softmax, beam_size=cfg.test.beam_size,
-                         max_target_length=cfg.test.max_target_length, lp_alpha=cfg.test.lp_alpha)
+    ocfg = _oracle_config(cfg)
     X = O.make_batch([raw[i] for i in range(sample_utts)])
     t0 = time.time()
     Y = O.build_test_model(X, W, ocfg, num_gpus=1, algo='kv')
     dt = time.time() - t0
     audio_s = sample_utts * raw.shape[1] / 100.0
-    return {'value': audio_s / dt, 'unit': 'audio-sec/sec', 'cores': int(cores), 'kind': 'port',
-            'sample': '%d of the 64 utterances (%.0f audio-s), beam %d, %d decode steps, numpy/OpenBLAS float32, '
+    return {'value': audio_s / dt, 'unit': 'audio-sec/sec', 'cores': _blas_threads(), 'kind': 'port',
+            'sample': '%d of the %d utterances (%.0f audio-s), beam %d, %d decode steps, numpy/OpenBLAS float32, '
                       'K/V-cache formulation of the reference algorithm; %.1f s wall'
-                      % (sample_utts, audio_s, cfg.test.beam_size, Y.shape[1], dt)}, Y
+                      % (sample_utts, raw.shape[0], audio_s, cfg.test.beam_size, Y.shape[1], dt)}, Y
+
+
+def decode_flops(cfg, t, steps, ref_shaped):
+    """Algorithmic FLOPs of `steps` decode steps of ONE utterance at beam K (1 MAC = 2 FLOP).
+    ref_shaped: the reference's own algorithm (self qkv over all i positions, cross K/V of the beam-tiled encoder
+    re-projected every step, model.py:559-633); else the K/V-cache algorithm."""
+    H, L, V, K = float(cfg.hidden_units), cfg.num_blocks, float(cfg.dst_vocab_size), cfg.test.beam_size
+    tot = 0.0
+    for i in range(1, steps + 1):
+        if ref_shaped:
+            per = L * (6 * H * H * i + 4 * H * H * t + (2 + 2 + 2 + 16 + 8) * H * H + 4 * H * (i + t)) + 2 * V * H
+        else:
+            per = L * (36 * H * H + 4 * H * (i + t)) + 2 * V * H
+        tot += K * per
+    return tot
+
+
+def cpu_baseline_ref_shaped(cfg, W, raw, steps=20):
+    """The LITERAL reference algorithm (oracle algo='ref') on ONE utterance for `steps` decode steps."""
+    from oracle import asr_oracle as O
+    ocfg = _oracle_config(cfg, mtl=steps - 1)               # loop runs min(T + 50, mtl) + 1 steps
+    X = O.make_batch([raw[0]])
+    t0 = time.time()
+    enc, _ = O.encoder(X, W, ocfg)
+    t_enc = time.time() - t0
+    t0 = time.time()
+    Y = O.beam_search(enc, W, ocfg, algo='ref')
+    t_dec = time.time() - t0
+    t = X.shape[1]
+    full_steps = min(t + 50, cfg.test.max_target_length) + 1
+    f_meas = decode_flops(cfg, t, Y.shape[1], True)
+    f_full = decode_flops(cfg, t, full_steps, True)
+    audio_s = raw.shape[1] / 100.0
+    t_full = t_enc + t_dec * f_full / f_meas
+    return {'value': audio_s / t_full, 'unit': 'audio-sec/sec', 'cores': _blas_threads(), 'kind': 'port',
+            'measured': {'utterances': 1, 'decode_steps': int(Y.shape[1]), 'encoder_s': round(t_enc, 3), 'decode_s': round(t_dec, 3),
+                         'decode_gflop': round(f_meas / 1e9, 1)},
+            'extrapolation': 'value = audio seconds / (encoder_s + decode_s x %.1f): the %d measured steps scaled to the '
+                             '%d steps the headline decode takes by the reference algorithm\'s own FLOP count '
+                             '(%.0f GFLOP for %d steps vs %.0f GFLOP measured; the K/V-cache algorithm needs %.0f GFLOP '
+                             'for the same %d steps)' % (f_full / f_meas, Y.shape[1], full_steps, f_full / 1e9, full_steps,
+                                                          f_meas / 1e9, decode_flops(cfg, t, full_steps, False) / 1e9, full_steps),
+            'sample': '1 of the utterances (%.0f audio-s), beam %d, %d decode steps of the literal model.py:559-633 algorithm '
+                      '(block-output cache, per-step re-projection), numpy/OpenBLAS float32' % (audio_s, cfg.test.beam_size, Y.shape[1])}
+
+
+def roofline_of(prof, precision):
+    overhead = [p for p in prof if p['name'].startswith('(')]
+    prof = [p for p in prof if not p['name'].startswith('(')]
+    tot_ms = sum(p['ms'] for p in prof) or 1.0
+    dom = max(prof, key=lambda p: p['ms'])
+    is_mfma = dom['flops'] > 0 and dom['name'].startswith(MFMA_KERNELS)
+    _, nprod, mfma_peak = PRECISION_INFO[precision]
+    if dom['name'].startswith('encoder_attention'):
+        nprod, mfma_peak = 1, PEAK_F32_MFMA_TFLOPS                    # f32 MFMA in every mode
+    if is_mfma:                                                        # matrix-bound: algorithmic FLOPs / time vs the MFMA peak
+        ach, peak, unit = dom['flops'] / (dom['ms'] * 1e-3) / 1e12, mfma_peak, 'TFLOP/s'
+    else:                                                              # HBM-bound: algorithmic BYTES / time vs the HBM peak
+        ach, peak, unit = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9, PEAK_HBM_GBS, 'GB/s'
+    r = {
+        'kernel': dom['name'], 'bound': 'mfma' if is_mfma else 'hbm', 'achieved': ach,
+        'peak': peak, 'unit': unit, 'frac': ach / peak,
+        'traffic': measured_traffic(dom['name'], precision),
+        'launches': dom['launches'], 'avg_us': 1000.0 * dom['ms'] / max(dom['launches'], 1),
+        'share_of_kernel_time': dom['ms'] / tot_ms,
+        # elapsed time of an EMPTY HIP-event pair, already subtracted from every bracket (asr_set_profile)
+        'event_pair_overhead_us': (1000.0 * overhead[0]['ms'] / max(overhead[0]['launches'], 1)) if overhead else None,
+    }
+    if is_mfma and nprod > 1:
+        # `achieved` counts ALGORITHMIC flops (2MNK); the matrix pipe executes nprod 16-bit products per f32 one
+        r['mfma_products_per_multiply'] = nprod
+        r['executed_frac'] = nprod * ach / peak
+    kernels = [{'name': p['name'], 'ms': round(p['ms'], 3), 'launches': p['launches'],
+                'tflops': round(p['flops'] / (p['ms'] * 1e-3) / 1e12, 2) if p['ms'] > 0 else 0.0,
+                'gbs': round(p['bytes'] / (p['ms'] * 1e-3) / 1e9, 1) if p['ms'] > 0 else 0.0}
+               for p in sorted(prof, key=lambda p: -p['ms'])]
+    return r, kernels
+
+
+def run_bucketed(args, rank, local_rank, world, rehearse):
+    """BASELINE configs 3/4: ragged utterances, length-bucketed batches sharded over the ranks (asr_amd/dist.py)."""
+    import torch
+    import torch.distributed as dist
+    from asr_amd import dist as D
+    from asr_amd import weights
+    from asr_amd.model import Engine
+
+    cfg = bench_config(args.beam, args.max_target_length, args.precision, args.vocab)
+    W = weights.random_init(cfg, seed=0)
+    eng = Engine(cfg, local_rank)
+    eng.load_weights(W)
+    n_total = world * args.utts_per_gpu
+    rng = np.random.default_rng(4242)                                  # every rank builds the same utterance list
+    raw_lens = [int(x) for x in rng.integers(200, 1501, size=n_total)]
+    # left3 / sub3 stacking by the library's own front-end kernel (fea.py:142-149), outside the timed region
+    feats = [eng.stack_frames(rng.standard_normal((ln, 80)).astype(np.float32)) for ln in raw_lens]
+    lengths = [len(f) for f in feats]
+    batches = D.bucket_batches(lengths, args.tokens_per_batch)
+    costs = [D.batch_cost(len(b), max(lengths[i] for i in b), args.beam, args.max_target_length) for b in batches]
+    owners = D.assign_batches(costs, world)
+    model_load = [sum(costs[i] for i in o) for o in owners]
+    busy = [0.0]
+
+    def decode_fn(X):
+        t0 = time.perf_counter()
+        Y = eng.decode(X)
+        busy[0] += time.perf_counter() - t0
+        return Y
+
+    device = None if (rehearse or world == 1) else torch.device('cuda', local_rank)
+
+    def step():
+        return D.decode_sharded(decode_fn, feats, args.tokens_per_batch, args.beam, args.max_target_length, rank=rank,
+                                world_size=world, device=device)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    busy[0] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        Y = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    busy_all = [busy[0]]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        bt = torch.tensor([busy[0]], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
+        parts = [torch.empty_like(bt) for _ in range(world)]
+        dist.all_gather(parts, bt)
+        busy_all = [float(p.item()) for p in parts]
+    if rank == 0:
+        audio_s = sum(raw_lens) / 100.0 * args.steps
+        out = {
+            'metric': 'decoded audio-sec/sec (RTFx) whole node, length-bucketed ragged batches, beam=%d' % args.beam,
+            'value': audio_s / elapsed, 'unit': 'audio-sec/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1000.0 * elapsed / max(args.steps, 1), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': PRECISION_INFO[args.precision][0], 'data': 'synthetic',
+            'config': {'workload': 'bucketed: %d utterances per GPU, T_raw ~ U[200,1500] (%.0f audio-s in all), 10-frame length '
+                                   'buckets closed above %d stacked frames (utils.py:285-323), %d batches dealt over %d rank(s) by '
+                                   'cost, host features (H2D inside the step), one all_gather of the hypotheses; char '
+                                   'architecture with V=%d, beam %d, max_target_length %d, random-init weights'
+                                   % (args.utts_per_gpu, sum(raw_lens) / 100.0, args.tokens_per_batch, len(batches), world, args.vocab,
+                                      args.beam, args.max_target_length),
+                       'parallelism': 'dp%d' % world, 'precision': args.precision, 'batches': len(batches),
+                       'batch_sizes': sorted(len(b) for b in batches)[::max(1, len(batches) // 16)],
+                       'range_retries': eng.range_retries()},
+            # per-rank seconds inside Engine.decode over the timed steps, and how even the deal was
+            'per_rank_busy_s': [round(b, 4) for b in busy_all],
+            'load_balance': {'measured_max_over_mean': max(busy_all) / (sum(busy_all) / len(busy_all)),
+                             'cost_model_max_over_mean': max(model_load) / (sum(model_load) / len(model_load))},
+            'hypotheses_shape': list(Y.shape),
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
 
 
 def main():
@@ -110,7 +297,13 @@ def main():
                     '28444 = word, 3205 = SEAME')
     ap.add_argument('--cpu-sample-utts', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt-precisions', action='store_true')
+    ap.add_argument('--alt-steps', type=int, default=3)
     ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_f16x3'), choices=sorted(PRECISION_INFO))
+    ap.add_argument('--workload', default='fixed', choices=['fixed', 'bucketed'])
+    ap.add_argument('--utts-per-gpu', type=int, default=64, help='--workload bucketed: utterances per GPU')
+    ap.add_argument('--tokens-per-batch', type=int, default=7000, help='--workload bucketed: stacked frames per batch '
+                    '(test.tokens_per_batch of the SEAME yaml)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -135,6 +328,13 @@ def main():
         else:
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
+    if args.workload == 'bucketed':
+        run_bucketed(args, rank, local_rank, world, rehearse)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     cfg = bench_config(args.beam, args.max_target_length, args.precision, args.vocab)
     W = weights.random_init(cfg, seed=0)
     eng = Engine(cfg, local_rank)
@@ -147,8 +347,8 @@ def main():
     width = args.max_target_length + 1
     front = (t_raw, 80, 3, 0, 3)
 
-    def step():
-        Y = eng.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
+    def step(e=eng):
+        Y = e.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
         if world > 1:      # gather the hypotheses (fixed width, padded with 3) on every rank
             buf = torch.full((n, width), 3, dtype=torch.int32)
             buf[:, :Y.shape[1]] = torch.from_numpy(Y)
@@ -196,44 +396,47 @@ def main():
                        # fp16's range (0 = every timed step ran on the fp16x3 kernels)
                        'range_retries': eng.range_retries()},
         }
-        # ---- roofline of the dominant kernel: HIP events around every launch of one extra pass ----
+        # ---- roofline of the dominant kernel: HIP events around every launch of one extra pass (the same half batches
+        # as the timed passes; the brackets serialise the host, so the two halves do not overlap in this pass) ----
         eng.set_profile(True)
         eng.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
         prof = eng.get_profile()
         eng.set_profile(False)
-        overhead = [p for p in prof if p['name'].startswith('(')]
-        prof = [p for p in prof if not p['name'].startswith('(')]
-        tot_ms = sum(p['ms'] for p in prof) or 1.0
-        dom = max(prof, key=lambda p: p['ms'])
-        ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['flops'] > 0 else dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
-        is_mfma = dom['flops'] > 0 and dom['name'].startswith('gemm')
-        _, nprod, mfma_peak = PRECISION_INFO[args.precision]
-        peak = mfma_peak if is_mfma else PEAK_HBM_GBS
-        out['roofline'] = {
-            'kernel': dom['name'], 'bound': 'mfma' if is_mfma else 'hbm', 'achieved': ach,
-            'peak': peak, 'unit': 'TFLOP/s' if is_mfma else 'GB/s', 'frac': ach / peak,
-            'traffic': measured_traffic(dom['name'], args.precision),
-            'launches': dom['launches'], 'avg_us': 1000.0 * dom['ms'] / max(dom['launches'], 1),
-            'share_of_kernel_time': dom['ms'] / tot_ms,
-            # elapsed time of an EMPTY HIP-event pair, already subtracted from every bracket (asr_set_profile)
-            'event_pair_overhead_us': (1000.0 * overhead[0]['ms'] / max(overhead[0]['launches'], 1)) if overhead else None,
-        }
-        if is_mfma and nprod > 1:
-            # `achieved` counts ALGORITHMIC flops (2MNK); the matrix pipe executes nprod bf16 products per f32 one
-            out['roofline']['mfma_products_per_multiply'] = nprod
-            out['roofline']['executed_frac'] = nprod * ach / peak
-        out['kernels'] = [{'name': p['name'], 'ms': round(p['ms'], 3), 'launches': p['launches'],
-                           'tflops': round(p['flops'] / (p['ms'] * 1e-3) / 1e12, 2) if p['ms'] > 0 else 0.0,
-                           'gbs': round(p['bytes'] / (p['ms'] * 1e-3) / 1e9, 1) if p['ms'] > 0 else 0.0}
-                          for p in sorted(prof, key=lambda p: -p['ms'])]
+        out['roofline'], out['kernels'] = roofline_of(prof, args.precision)
         if world == 1 and not args.no_cpu_baseline:
             cb, Yc = cpu_baseline(cfg, W, raw, min(args.cpu_sample_utts, n))
             m = min(Yc.shape[1], Y.shape[1])
             cb['hypotheses_match_gpu'] = bool(np.array_equal(Yc[:, :m], Y[:Yc.shape[0], :m]))
             out['cpu_baseline'] = cb
+            out['cpu_baseline_ref_shaped'] = cpu_baseline_ref_shaped(cfg, W, raw)
+        if world == 1 and not args.no_alt_precisions:
+            # the other dense-layer arithmetics on the same batch, timed by this same run (fresh handle each; the
+            # headline handle is closed first so that only one set of weights and caches is resident)
+            eng.close()
+            eng = None
+            alts = {}
+            for prec in ('f32_bf16x6', 'f32', 'bf16'):
+                if prec == args.precision:
+                    continue
+                e2 = Engine(bench_config(args.beam, args.max_target_length, prec, args.vocab), local_rank)
+                e2.load_weights(W)
+                Ya = step(e2)                                            # warm-up
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(args.alt_steps):
+                    Ya = step(e2)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - ta) / max(args.alt_steps, 1)
+                m = min(Ya.shape[1], Y.shape[1])
+                alts[prec] = {'value': n * t_raw / 100.0 / dt, 'unit': 'audio-sec/sec', 'ms_per_step': 1000.0 * dt,
+                              'steps': args.alt_steps, 'dtype': PRECISION_INFO[prec][0].split(' (')[0],
+                              'hypotheses_match': bool(Ya.shape == Y.shape and np.array_equal(Ya[:, :m], Y[:, :m]))}
+                e2.close()
+            out['alt_precisions'] = alts
         print(json.dumps(out), flush=True)
 
-    eng.close()
+    if eng is not None:
+        eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
