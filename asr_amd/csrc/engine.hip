@@ -26,6 +26,7 @@ std::string g_create_error;
 constexpr int NOALLOC_MAX_UTTS = 1024;
 constexpr int NOALLOC_DOUBLES_PER_UTT = 128;
 constexpr int MAX_DEVICES = 64;
+constexpr int MAX_VIEWS = 4;        // sub-batches a beam search may run as (asr_config.sub_batches)
 static __device__ __align__(256) double g_norm_scratch[NOALLOC_MAX_UTTS * NOALLOC_DOUBLES_PER_UTT];
 double* g_norm_scratch_ptr[MAX_DEVICES] = {};      // device address of g_norm_scratch on device d (null: not resolved yet)
 
@@ -95,13 +96,13 @@ struct asr_handle {
     int32_t* cand_tokens = nullptr;
     std::vector<float*> kcache, vcache;
     BeamState beam{};
-    int32_t* done_host = nullptr;       // pinned, [2][max_target_length + 8]
-    std::vector<hipEvent_t> step_events;    // [2][8]
+    int32_t* done_host = nullptr;       // pinned, [MAX_VIEWS][max_target_length + 8]
+    std::vector<hipEvent_t> step_events;    // [MAX_VIEWS][8]
     // The beam search of a batch may run as two independent halves (utterances are independent) on two streams,
     // so that the launch gaps and tails of one half's kernels are filled by the other's (ASR_AMD_SUBBATCH=1 disables)
-    hipStream_t stream2 = nullptr;
+    hipStream_t xstream[3] = {nullptr, nullptr, nullptr};   // streams of sub-batches 1..3 (sub-batch 0 runs on `stream`)
     hipEvent_t fork_ev = nullptr;
-    int sub_batches = 0;                // 0 = automatic (two halves from 320 rows), 1 = never, 2 = whenever n >= 2
+    int sub_batches = 0;                // 0 = automatic (two halves from 320 rows), 1 = never, 2..4 = that many parts whenever n allows
 
     // profile
     int profile = 0;
@@ -481,7 +482,7 @@ int ensure_decoder_capacity(asr_handle* h, int n)
         rc |= dev_alloc_t(h, &h->beam.preds[i], R * width);
         rc |= dev_alloc_t(h, &h->beam.anc[i], R * width);
     }
-    rc |= dev_alloc_t(h, &h->beam.pos, 16);              // pos / done / unfinished of up to two sub-batches
+    rc |= dev_alloc_t(h, &h->beam.pos, 16);              // pos / done / unfinished of up to MAX_VIEWS sub-batches, 4 ints each
     rc |= dev_alloc_t(h, &h->beam.tokens, R);
     rc |= dev_alloc_t(h, &h->beam.parents, R);
     rc |= dev_alloc_t(h, &h->beam.live, R * width);
@@ -763,21 +764,26 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     // (kernels of one half fill the launch gaps and tails of the other's).  The joint loop of the reference ends
     // when every utterance has finished: a half that ends earlier is padded with 3, which is what further steps
     // append to finished beams (model.py:253) without changing their order or scores.
-    const bool want2 = h->sub_batches == 2 ? n >= 2 : (h->sub_batches == 0 && R >= 320);   // auto: each half still fills the GPU
-    const int nviews = (want2 && !tr) ? 2 : 1;      // profile mode keeps the halves: its brackets time the shapes the timed passes launch
-    DecView views[2];
-    const int n_first = nviews == 2 ? (n + 1) / 2 : n;
-    views[0] = make_view(h, 0, 0, n_first, t, h->stream);
-    if (nviews == 2) {
-        views[1] = make_view(h, 1, n_first, n - n_first, t, h->stream2);
+    int nviews = h->sub_batches >= 2 ? std::min(h->sub_batches, n) : (h->sub_batches == 0 && R >= 320 ? 2 : 1);   // auto: each half still fills the GPU
+    if (tr) nviews = 1;                             // (profile mode keeps the parts: its brackets time the shapes the timed passes launch)
+    DecView views[MAX_VIEWS];
+    for (int vi = 0, n0 = 0; vi < nviews; ++vi) {   // the first n % nviews parts get one utterance more
+        const int nv = n / nviews + (vi < n % nviews ? 1 : 0);
+        views[vi] = make_view(h, vi, n0, nv, t, vi == 0 ? h->stream : h->xstream[vi - 1]);
+        n0 += nv;
+    }
+    if (nviews > 1) {
         HIP_TRY(h, hipEventRecord(h->fork_ev, h->stream));                                          // encoder + cross K/V done
-        HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->fork_ev, 0));
+        for (int vi = 1; vi < nviews; ++vi) HIP_TRY(h, hipStreamWaitEvent(views[vi].stream, h->fork_ev, 0));
     }
     for (int v = 0; v < nviews; ++v) HIP_TRY(h, launch_beam_init(views[v].beam, views[v].n, K, views[v].stream));
     constexpr int LOOKAHEAD = 3;
-    bool ended[2] = {false, nviews < 2};
-    for (int s = 1; s <= max_steps && !(ended[0] && ended[1]); ++s) {
-        const bool active[2] = {!ended[0], !ended[1]};
+    bool ended[MAX_VIEWS];
+    for (int vi = 0; vi < MAX_VIEWS; ++vi) ended[vi] = vi >= nviews;
+    auto all_ended = [&]() { for (int vi = 0; vi < nviews; ++vi) if (!ended[vi]) return false; return true; };
+    for (int s = 1; s <= max_steps && !all_ended(); ++s) {
+        bool active[MAX_VIEWS];
+        for (int vi = 0; vi < MAX_VIEWS; ++vi) active[vi] = !ended[vi];
         rc = run_decode_step(h, views, active, nviews, t);
         if (rc) return rc;
         if (tr && s <= tr->steps) {
@@ -813,7 +819,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
             }
         }
     }
-    int lens[2] = {0, 0};
+    int lens[MAX_VIEWS] = {0, 0, 0, 0};
     for (int vi = 0; vi < nviews; ++vi) {
         HIP_TRY(h, hipStreamSynchronize(views[vi].stream));
         int32_t posd[2] = {0, 0};
@@ -822,7 +828,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
         if (!posd[1] || lens[vi] < 1 || lens[vi] > max_steps)
             return fail(h, ASR_ERR_HIP, "beam search loop ended in an inconsistent state");
     }
-    const int len = std::max(lens[0], lens[1]);
+    const int len = *std::max_element(lens, lens + MAX_VIEWS);
     if ((int64_t)n * len > y_capacity) return fail(h, ASR_ERR_CAPACITY, "Y too small: need n * " + std::to_string(len) + " int32");
     const int width = h->beam.width;
     for (int vi = 0; vi < nviews; ++vi) {
@@ -943,7 +949,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     if (cfg->max_target_length < 1 || cfg->max_target_length > 4000) return bad("max_target_length must be in 1..4000");
     if (cfg->ff_activation < ASR_FF_RELU || cfg->ff_activation > ASR_FF_SWISH) return bad("unknown ff_activation");
     if (cfg->precision < ASR_PRECISION_F32 || cfg->precision > ASR_PRECISION_F32_F16X3) return bad("unknown precision");
-    if (cfg->sub_batches < 0 || cfg->sub_batches > 2) return bad("sub_batches must be 0 (default), 1 or 2");
+    if (cfg->sub_batches < 0 || cfg->sub_batches > MAX_VIEWS) return bad("sub_batches must be 0 (default) or 1..4");
     for (int i = 0; i < 2; ++i)
         if (cfg->reserved[i]) return bad("reserved fields must be zero");
     int ndev = 0;
@@ -983,14 +989,15 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     if ((e = hipMemset(h->range_flag, 0, 16)) != hipSuccess) return hip_fail(e, "hipMemset");
     if ((e = hipEventCreate(&h->pe0)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->pe1)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-    if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    for (auto& xs : h->xstream)
+        if ((e = hipStreamCreateWithFlags(&xs, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
     if ((e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if (cfg->sub_batches) h->sub_batches = cfg->sub_batches;
-    else if (const char* sb = getenv("ASR_AMD_SUBBATCH")) h->sub_batches = std::max(0, std::min(2, atoi(sb)));
-    h->step_events.resize(16);
+    else if (const char* sb = getenv("ASR_AMD_SUBBATCH")) h->sub_batches = std::max(0, std::min(MAX_VIEWS, atoi(sb)));
+    h->step_events.resize(8 * MAX_VIEWS);
     for (auto& ev : h->step_events)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->done_host), (size_t)2 * (cfg->max_target_length + 8) * sizeof(int32_t), 0)) != hipSuccess)
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->done_host), (size_t)MAX_VIEWS * (cfg->max_target_length + 8) * sizeof(int32_t), 0)) != hipSuccess)
         return hip_fail(e, "hipHostMalloc");
     h->cross_k.assign(h->L, nullptr); h->cross_v.assign(h->L, nullptr);
     h->kcache.assign(h->L, nullptr); h->vcache.assign(h->L, nullptr);
@@ -1009,7 +1016,7 @@ void asr_destroy(asr_handle* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    for (auto xs : h->xstream) if (xs) (void)hipStreamSynchronize(xs);
     for (auto& kv : h->allocs) (void)hipFree(kv.first);
     if (h->range_flag) (void)hipFree(h->range_flag);
     if (h->done_host) (void)hipHostFree(h->done_host);
@@ -1017,7 +1024,7 @@ void asr_destroy(asr_handle* h)
     if (h->pe0) (void)hipEventDestroy(h->pe0);
     if (h->pe1) (void)hipEventDestroy(h->pe1);
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    for (auto xs : h->xstream) if (xs) (void)hipStreamDestroy(xs);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -402,6 +402,10 @@ hipError_t launch_split_epi(const GemmArgs& a, int tile, hipStream_t s)
         case 5: return launch_split_tile<5, 1, 4, EPI, NPROD>(a, s);     // 160 x 128
         case 7: return launch_split_tile<2, 2, 4, EPI, NPROD>(a, s);     // 64 x 256, 4 waves of 64 columns
 #endif
+#ifdef ASR_GEMM_ALL_TILES
+        case 3: return launch_split_tile<1, 1, 4, EPI, NPROD>(a, s);     // 32 x 128
+        case 4: return launch_split_tile<1, 1, 8, EPI, NPROD>(a, s);     // 32 x 256, 8 waves of 32 columns
+#endif
         case 9: return launch_split_tile<2, 1, 8, EPI, NPROD>(a, s);     // 64 x 256, 8 waves of 32 columns
         default: return launch_split_tile<2, 1, 4, EPI, NPROD>(a, s);    // 64 x 128
     }

@@ -55,8 +55,8 @@ def asr_config_from(config, device=0):
     c.precision = _lib.PRECISIONS[prec]
     # build extension: 1 = one run of kernels per batch, 2 = two independent halves on two streams, None = library default
     sb = int(t.sub_batches or 0)
-    if sb not in (0, 1, 2):
-        raise ValueError('test.sub_batches must be 1 or 2')
+    if sb not in (0, 1, 2, 3, 4):
+        raise ValueError('test.sub_batches must be 1..4')
     c.sub_batches = sb
     return c, prec
 

@@ -70,8 +70,8 @@ typedef struct asr_config {
     int32_t device;                      /* HIP device ordinal this handle lives on       */
     int32_t precision;                   /* enum asr_precision (build extension; YAML key test.precision; the Python host's default
                                             is F32_F16X3, a zeroed struct means F32) */
-    int32_t sub_batches;                 /* 1 = beam-search the batch as one run of kernels, 2 = as two independent halves on
-                                            two streams (same results: utterances are independent), 0 = env
+    int32_t sub_batches;                 /* 1 = beam-search the batch as one run of kernels, 2..4 = as that many independent
+                                            parts on their own streams (same results: utterances are independent), 0 = env
                                             ASR_AMD_SUBBATCH or automatic (two halves from 320 beam rows);
                                             build extension, YAML key test.sub_batches */
     int32_t reserved[2];                 /* must be zero                                  */

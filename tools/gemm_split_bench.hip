@@ -1,7 +1,9 @@
 // Micro-benchmark of the bf16-plane GEMM (gemm_split.hip) on the decode / encoder shapes, every tile variant, checked
 // against the exact-f32 kernel (development tool, not part of the library).
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/gemm_split_bench.hip asr_amd/csrc/gemm_f32.o asr_amd/csrc/gemm_split.o -o tools/gemm_split_bench
-// run:   tools/gemm_split_bench [reps] [shape prefix] [nprod] [tile] [split]
+// run:   tools/gemm_split_bench [reps] [shape prefix] [nprod] [tile] [split] [cold]
+//        cold = 1: every timed launch reads another copy of the weights (a 640 MB pool, beyond the 256 MB Infinity Cache),
+//        as in the decode pipeline where a step streams 470 MB of weights between two uses of the same matrix
 #include "../asr_amd/csrc/asr_common.h"
 #include <math.h>
 #include <stdio.h>
@@ -19,12 +21,18 @@ int main(int argc, char** argv)
     const char* only = argc > 2 && argv[2][0] != '-' ? argv[2] : nullptr;
     const int nprod = argc > 3 ? atoi(argv[3]) : 6;
     const int only_tile = argc > 4 ? atoi(argv[4]) : 0, only_split = argc > 5 ? atoi(argv[5]) : 0;
+    const bool cold = argc > 6 && atoi(argv[6]) != 0;
+    const size_t POOL = (size_t)640 << 20;
     std::vector<Shape> shapes = {
         {"qkv   ", 640, 3072, 1024, EPI_PARTIAL}, {"proj  ", 640, 1024, 1024, EPI_PARTIAL},
         {"glu   ", 640, 8192, 1024, EPI_GLU},     {"xgluP ", 640, 8192, 1024, EPI_PARTIAL}, {"xgluB ", 640, 8192, 1024, EPI_BIAS},     {"ffn2  ", 640, 1024, 4096, EPI_PARTIAL},
         {"logits", 640, 3900, 1024, EPI_PARTIAL},
         {"hqkv  ", 320, 3072, 1024, EPI_PARTIAL}, {"hproj ", 320, 1024, 1024, EPI_PARTIAL},
         {"hglu  ", 320, 8192, 1024, EPI_GLU},     {"hffn2 ", 320, 1024, 4096, EPI_PARTIAL},
+        // fixed cost vs cost per k-tile: the same N at shorter K
+        {"kglu256", 320, 8192, 256, EPI_GLU}, {"kglu512", 320, 8192, 512, EPI_GLU}, {"kgluP256", 320, 8192, 256, EPI_PARTIAL},
+        {"kgluP1024", 320, 8192, 1024, EPI_PARTIAL}, {"kproj256", 320, 1024, 256, EPI_PARTIAL}, {"kproj512", 320, 1024, 512, EPI_PARTIAL},
+        {"kGglu256", 640, 8192, 256, EPI_GLU}, {"kGglu512", 640, 8192, 512, EPI_GLU},
         {"encqkv", 21376, 3072, 1024, EPI_BIAS},
         {"encglu", 21376, 8192, 1024, EPI_GLU},   {"encff2", 21376, 1024, 4096, EPI_BIAS},
         {"encprj", 21376, 1024, 1024, EPI_BIAS},
@@ -38,7 +46,7 @@ int main(int argc, char** argv)
     float *A, *W, *C, *Cref, *bias;
     uint16_t* Wp;
     CK(hipMalloc(&A, maxA * 4)); CK(hipMalloc(&W, maxW * 4)); CK(hipMalloc(&C, maxC * 4)); CK(hipMalloc(&Cref, maxC * 4));
-    CK(hipMalloc(&bias, 65536 * 4)); CK(hipMalloc(&Wp, (maxW + 32 * 4096) * 2 * npl));
+    CK(hipMalloc(&bias, 65536 * 4)); CK(hipMalloc(&Wp, std::max((maxW + 32 * 4096) * 2 * npl, cold ? POOL : (size_t)0)));
     std::vector<float> hA(maxA), hW(maxW), hC(maxC), hR(maxC);
     srand(1);
     for (auto& v : hA) v = (rand() / (float)RAND_MAX - 0.5f) * 2.0f;
@@ -55,7 +63,9 @@ int main(int argc, char** argv)
         (void)cnt;
         planes.resize(gemm_split_weight_elems(s.N, s.K, npl));
         gemm_split_weights_host(hW.data(), s.N, s.K, nprod, planes.data());
-        CK(hipMemcpy(Wp, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+        const size_t wbytes = (planes.size() * 2 + 255) / 256 * 256;
+        const int copies = cold ? (int)std::max<size_t>(1, POOL / wbytes) : 1;
+        for (int c = 0; c < copies; ++c) CK(hipMemcpy(reinterpret_cast<char*>(Wp) + c * wbytes, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
         const bool dec = s.M <= 640;
         const int ldc = s.epi == EPI_GLU ? s.N / 2 : s.N;
         // reference: exact-f32 kernel, unsplit
@@ -73,7 +83,7 @@ int main(int argc, char** argv)
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("%s M=%5d N=%5d K=%5d exact f32 (unsplit)      %8.1f us\n", s.name, s.M, s.N, s.K, ms * 1e3 / reps);
         }
-        for (int tile : {2, 7, 9}) {
+        for (int tile : {2, 3, 4, 9}) {
             for (int split = 1; split <= (dec && s.epi == EPI_PARTIAL ? 16 : 1); split *= 2) {
                 if (split > 1 && s.K / split < 128) continue;
                 if ((only_tile && tile != only_tile) || (only_split && split != only_split)) continue;
@@ -92,7 +102,10 @@ int main(int argc, char** argv)
                 }
                 for (int i = 0; i < 3; ++i) launch_gemm_split(a, nprod, tile, st);
                 CK(hipEventRecord(e0, st));
-                for (int i = 0; i < reps; ++i) launch_gemm_split(a, nprod, tile, st);
+                for (int i = 0; i < reps; ++i) {
+                    a.Wp = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(Wp) + (size_t)(i % copies) * wbytes);
+                    launch_gemm_split(a, nprod, tile, st);
+                }
                 CK(hipEventRecord(e1, st));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
