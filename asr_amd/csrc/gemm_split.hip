@@ -406,6 +406,7 @@ hipError_t launch_split_epi(const GemmArgs& a, int tile, hipStream_t s)
         case 3: return launch_split_tile<1, 1, 4, EPI, NPROD>(a, s);     // 32 x 128
         case 4: return launch_split_tile<1, 1, 8, EPI, NPROD>(a, s);     // 32 x 256, 8 waves of 32 columns
 #endif
+        case 6: return launch_split_tile<3, 1, 8, EPI, NPROD>(a, s);     // 96 x 256, 8 waves of 32 columns
         case 9: return launch_split_tile<2, 1, 8, EPI, NPROD>(a, s);     // 64 x 256, 8 waves of 32 columns
         default: return launch_split_tile<2, 1, 4, EPI, NPROD>(a, s);    // 64 x 128
     }
@@ -514,11 +515,37 @@ bool gemm_split_weights_host(const float* w, int n, int k, int nprod, uint16_t* 
 // 8-wave workgroup splits an A tile once for 256 columns instead of 128 (the split is ~15 % of the fp16x3 kernel's time) at
 // the same number of waves per CU: 5-10 % faster wherever there are enough 256-column tiles to go round, i.e. everywhere
 // but the 1024 x 1024 projections of the decode rows.
-int gemm_split_pick_tile(int M, int N, int K, int split_k, int epilogue)
+static int legacy_tile(int M, int N, int K)
 {
-    (void)split_k; (void)epilogue;
     const long t256 = (long)((M + 63) / 64) * ((N + 255) / 256);
     return t256 * std::max(1, K / 1024) >= 64 ? 9 : 2;
+}
+
+// The 8-wave kernels hold 158-222 registers per lane: ONE workgroup per CU, so a launch of more than 256 workgroups runs
+// in rounds and the last round leaves most of the chip idle (640 x 8192 as 64 x 256 tiles = 320 workgroups = two rounds:
+// 55 us; as 96 x 256 tiles = 224 workgroups = one round: 42 us).  For the decode rows of a whole batch (M = 640: seven
+// 96-row tiles waste 5 % of the rows) the 96 x 256 tile is taken when tiles x K-slices lands in (205, 256]: measured with
+// tools/gemm_split_bench.hip (cold weights), GLU 55 -> 42 us, FFN2 27 -> 23 us (8 slices), logits 26 -> 23 us (2 slices);
+// QKV (84 tiles x 2 = 168 workgroups) stays on 64 x 256 x 2 slices (240 workgroups: 17 us against 20 us).
+// Returns the number of K-slices to run 96 x 256 tiles with, 0 = do not.
+static int tall_slices(int M, int N, int K, bool may_split)
+{
+    if (M <= 576 || M > 4096 || legacy_tile(M, N, K) != 9) return 0;
+    const int rows = (M + 95) / 96 * 96;
+    if (rows * 100 > M * 106) return 0;                            // more than 6 % of padded rows
+    const long tiles = (long)(rows / 96) * ((N + 255) / 256);
+    int split = 1;
+    if (may_split)
+        while (split * 2 <= ASR_MAX_SPLITK && tiles * split * 2 <= 256 && K / (split * 2) >= 128) split *= 2;
+    const long wgs = tiles * split;
+    return (wgs > 205 && wgs <= 256) ? split : 0;
+}
+
+int gemm_split_pick_tile(int M, int N, int K, int split_k, int epilogue)
+{
+    const int ts = tall_slices(M, N, K, epilogue == EPI_PARTIAL);
+    if (ts && ts == std::max(1, split_k)) return 6;
+    return legacy_tile(M, N, K);
 }
 
 // K-slices for the decode-time projections: a k-tile costs a workgroup about 0.3 us while it waits on its own loads and
@@ -527,7 +554,8 @@ int gemm_split_pick_tile(int M, int N, int K, int split_k, int epilogue)
 // bench (tools/splits_sweep.sh).
 int gemm_split_pick_split_k(int M, int N, int K, int nprod)
 {
-    const int bn = gemm_split_pick_tile(M, N, K, 1, 0) == 9 ? 256 : 128;
+    if (const int ts = tall_slices(M, N, K, true)) return ts;
+    const int bn = legacy_tile(M, N, K) == 9 ? 256 : 128;
     const double tiles = (double)((M + 63) / 64) * ((N + bn - 1) / bn);
     if (tiles * (bn / 128) >= 1024) return 1;
     const double pipe_us = 0.45 * (nprod == 6 ? 1.0 : nprod == 3 || nprod == 13 ? 0.6 : 0.4), lat_us = 0.3;
