@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libasr_amd.so')
+# ASR_AMD_LIB: development switch (A/B timing of two builds on one GPU box); the product loads the in-tree library
+LIB_PATH = os.environ.get('ASR_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libasr_amd.so')
 
 ASR_OK = 0
 FF_ACTIVATIONS = {'relu': 0, 'glu': 1, 'sigmoid': 2, 'tanh': 3, 'swish': 4}

@@ -101,7 +101,7 @@ struct BeamState {       // device pointers; double-buffered arrays are indexed 
     int32_t* live;             // [B][K*width] (position << 5 | slot) of every cache row some beam of the utterance still
                                // descends from, positions 0 .. *pos-1, ordered by position then slot
     int32_t* live_cnt;         // [B] entries in live
-    int32_t* pos;              // [1] decode steps done so far (= position of the token fed next)
+    int32_t* pos;              // [4] pos = decode steps done so far (= position of the token fed next), done, unfinished, arrivals
     int32_t* done;             // [1] loop has ended
     int32_t* unfinished;       // [1] scratch counter
     int32_t* tokens;           // [R] last tokens (trace)
@@ -110,8 +110,10 @@ struct BeamState {       // device pointers; double-buffered arrays are indexed 
     int limit;                 // min(T + 50, max_target_length)
 };
 hipError_t launch_beam_init(const BeamState& st, int b, int k, hipStream_t s);
+// one pruning step + the next step's decoder input (y_next[r] = E[token r] * mult + pe[pos + 1]) + the loop condition
 hipError_t launch_beam_step(const BeamState& st, const float* cand_scores, const int32_t* cand_tokens,
-                            int b, int k, hipStream_t s);
+                            int b, int k, const float* E, const float* pe, float mult, int hidden, float* y_next,
+                            hipStream_t s);
 // stand-alone pruning step for asr_op_beam_step
 hipError_t launch_beam_prune(const float* scores, const int32_t* finished, const float* cand_scores,
                              const int32_t* cand_tokens, int b, int k, float* new_scores, int32_t* tokens,

@@ -696,7 +696,8 @@ int step_tail(asr_handle* h, const DecView& v, const StepCtx& c)
     }
     {
         ProfScope ps(h, "beam_step", 0, 0, s);
-        HIP_TRY(h, launch_beam_step(st, v.cand_scores, v.cand_tokens, c.n, K, s));                  // :280-301
+        const float mult = h->cfg.scale_embedding ? (float)sqrt((double)h->H) : 1.0f;
+        HIP_TRY(h, launch_beam_step(st, v.cand_scores, v.cand_tokens, c.n, K, h->emb, h->pe, mult, H, v.y0, s));   // :280-301, :569-576
     }
     return ASR_OK;
 }
@@ -705,13 +706,13 @@ int step_tail(asr_handle* h, const DecView& v, const StepCtx& c)
 // (rocprofv3 kernel trace of both queues) is that two kernels that share the CUs each take about the sum of their solo
 // times - also an HBM-bound attention kernel beside a matrix-bound GEMM - so forcing the views half a block apart with
 // events (tried: -12 %) buys nothing; the gain of two views (+3.3 %) is the launch gaps and tails they fill for each other.
-int run_decode_step(asr_handle* h, DecView* views, const bool* active, int nviews, int t)
+int run_decode_step(asr_handle* h, DecView* views, const bool* active, int nviews, int t, bool first_step)
 {
     for (int vi = 0; vi < nviews; ++vi) {
         if (!active[vi]) continue;
         const DecView& v = views[vi];
         const StepCtx c = step_ctx(h, v);
-        int rc = step_head(h, v, c);
+        int rc = first_step ? step_head(h, v, c) : ASR_OK;           // later steps: beam_step_kernel wrote the decoder input
         if (rc) return rc;
         for (int l = 0; l < h->L; ++l) {
             if ((rc = step_attention_half(h, v, c, l, t))) return rc;
@@ -784,7 +785,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     for (int s = 1; s <= max_steps && !all_ended(); ++s) {
         bool active[MAX_VIEWS];
         for (int vi = 0; vi < MAX_VIEWS; ++vi) active[vi] = !ended[vi];
-        rc = run_decode_step(h, views, active, nviews, t);
+        rc = run_decode_step(h, views, active, nviews, t, s == 1);
         if (rc) return rc;
         if (tr && s <= tr->steps) {
             const int buf = s & 1;

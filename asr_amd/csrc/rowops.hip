@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(const float* scores, co
 __global__ void beam_init_kernel(BeamState st, int rows, int k)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r == 0) { *st.pos = 0; *st.done = 0; *st.unfinished = 0; }
+    if (r == 0) { *st.pos = 0; *st.done = 0; *st.unfinished = 0; st.pos[3] = 0; }
     if (r >= rows) return;
     if (r % k == 0) st.live_cnt[r / k] = 0;                  // no history before the first step
     st.scores[0][r] = (r % k == 0) ? 0.0f : -1e10f;          // model.py:264-265
@@ -626,7 +626,12 @@ __global__ void beam_init_kernel(BeamState st, int rows, int k)
     st.preds[0][(size_t)r * st.width] = 2;                   // <S>  (:263)
 }
 
-__global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* cand_scores, const int32_t* cand_tokens, int k)
+// Also does what two more launches per step used to do: the embedding of the tokens just chosen (the next step's decoder
+// input, model.py:569-576) for the utterance's own K rows, and - in the workgroup that finishes last - the loop condition
+// of model.py:305-312 (beam_loop_ctl_kernel's arithmetic).
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* cand_scores, const int32_t* cand_tokens, int k,
+                                                         const float* __restrict__ E, const float* __restrict__ pe, float mult,
+                                                         int hidden, float* __restrict__ y_next)
 {
     if (*st.done) return;
     __shared__ BeamLds L;
@@ -649,10 +654,16 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
         st.tokens[r] = L.ntok[tid];
         st.parents[r] = u * k + L.npar[tid];
     }
-    if (tid == 0) {
-        int any = 0;
-        for (int i = 0; i < k; ++i) any |= (L.ntok[i] != 3);
-        if (any) atomicAdd(st.unfinished, 1);
+    // decoder input of the next step: E[token] * mult + timing signal of position pos + 1, rows of this utterance
+    {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(pe + (size_t)(pos + 1) * hidden);
+        const int h4 = hidden >> 2;
+        for (int i = tid; i < k * h4; i += blockDim.x) {
+            const int beam = i / h4, c4 = i - beam * h4;
+            f32x4 v = reinterpret_cast<const f32x4*>(E + (size_t)L.ntok[beam] * hidden)[c4];
+            if (mult != 1.0f) v = v * mult;
+            reinterpret_cast<f32x4*>(y_next + (size_t)(u * k + beam) * hidden)[c4] = v + p4[c4];
+        }
     }
     // Live rows of the K/V cache for the next step's self-attention: (position j, slot) pairs that at least one
     // of the new beams descends from, j = 0..pos, ordered by j then slot.  Each thread owns a contiguous run of
@@ -688,17 +699,22 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
         }
         if (tid == 255) st.live_cnt[u] = scan[255];
     }
-}
-
-// loop condition (model.py:305-312): continue while any(!finished) and steps_done <= limit
-__global__ void beam_loop_ctl_kernel(BeamState st)
-{
-    if (*st.done) return;
-    const int pos = *st.pos + 1;
-    *st.pos = pos;
-    const int any = *st.unfinished;
-    *st.unfinished = 0;
-    if (!(any > 0 && pos <= st.limit)) *st.done = 1;
+    // Loop condition, by whichever workgroup arrives last.  The counters are device-scope atomics; pos / done are plain
+    // words that only later kernels of the stream read (every workgroup of this launch has read them before it arrives).
+    if (tid == 0) {
+        int any = 0;
+        for (int i = 0; i < k; ++i) any |= (L.ntok[i] != 3);
+        if (any) atomicAdd(st.unfinished, 1);
+        __threadfence();                                      // the count before the ticket
+        int32_t* arrive = st.pos + 3;
+        if (atomicAdd(arrive, 1) == (int)gridDim.x - 1) {
+            const int any_total = atomicExch(st.unfinished, 0);
+            atomicExch(arrive, 0);
+            const int np = pos + 1;
+            *st.pos = np;
+            if (!(any_total > 0 && np <= st.limit)) *st.done = 1;
+        }
+    }
 }
 
 }  // namespace
@@ -855,11 +871,10 @@ hipError_t launch_beam_init(const BeamState& st, int b, int k, hipStream_t s)
 }
 
 hipError_t launch_beam_step(const BeamState& st, const float* cand_scores, const int32_t* cand_tokens, int b, int k,
-                            hipStream_t s)
+                            const float* E, const float* pe, float mult, int hidden, float* y_next, hipStream_t s)
 {
-    if (!beam_state_ok(st, b, k) || !cand_scores || !cand_tokens) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(beam_step_kernel, dim3(b), dim3(256), 0, s, st, cand_scores, cand_tokens, k);
-    hipLaunchKernelGGL(beam_loop_ctl_kernel, dim3(1), dim3(1), 0, s, st);
+    if (!beam_state_ok(st, b, k) || !cand_scores || !cand_tokens || !E || !pe || !y_next || (hidden & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(beam_step_kernel, dim3(b), dim3(256), 0, s, st, cand_scores, cand_tokens, k, E, pe, mult, hidden, y_next);
     return hipGetLastError();
 }
 
