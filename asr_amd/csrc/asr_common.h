@@ -87,8 +87,8 @@ hipError_t launch_embed_shifted(const float* E, const int32_t* Y, int rows, int 
                                 int hidden, float* y, hipStream_t s);
 // row_loss[r] = (Y[r] != 0) * (logsumexp(logits[r]) - logits[r][Y[r]])
 hipError_t launch_xent_rows(const float* logits, const int32_t* Y, int rows, int vocab, float* row_loss, hipStream_t s);
-// kv [n*t, 2*hidden] (k | v) -> k, v [n][heads][t][64]
-hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, float* k, float* v, hipStream_t s);
+// kv [n*t, 2*hidden] (k | v) -> k, v [n][heads][t][64], float32 or (kv_bf16) bf16 rounded to nearest even
+hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, void* k, void* v, int kv_bf16, hipStream_t s);
 // logits [nsplit][rows][vocab] split-K slabs (summed in slab order; nsplit = 1: plain logits)
 hipError_t launch_log_softmax_topk(const float* logits, int nsplit, size_t split_stride, int rows, int vocab, int k,
                                    float* values, int32_t* indices, const int32_t* done, hipStream_t s);
@@ -129,8 +129,9 @@ struct SelfAttnArgs {
     const float* qkv;      // [nsplit][R][3*hidden] partial qkv projections (q | k | v), bias not yet added
     int nsplit; size_t split_stride;
     const float* bias;     // [3*hidden]
-    float* kcache;         // [b][heads][width][K][64] for this block: head-major, then position, beam slot inside
-    float* vcache;
+    void* kcache;          // [b][heads][width][K][64] for this block: head-major, then position, beam slot inside;
+    void* vcache;          // float32, or bf16 when kv_bf16
+    int kv_bf16;
     const int32_t* anc0;   // BeamState.anc[0], anc[1]
     const int32_t* anc1;
     const int32_t* live;   // BeamState.live, live_cnt
@@ -147,8 +148,9 @@ struct CrossAttnArgs {
     const float* qpart;    // [nsplit][R][hidden] partial q projections
     int nsplit; size_t split_stride;
     const float* qbias;    // [hidden]
-    const float* kc;       // [b][heads][t][64] + ASR_XATT_SLACK_ROWS rows of 64 floats that may be read (not used)
-    const float* v;        // [b][heads][t][64] + the same slack
+    const void* kc;        // [b][heads][t][64] + ASR_XATT_SLACK_ROWS rows of 64 values that may be read (not used)
+    const void* v;         // [b][heads][t][64] + the same slack; float32, or bf16 when kv_bf16
+    int kv_bf16;
     const int32_t* pad2;   // [b][t] + ASR_XATT_SLACK_ROWS ints of slack
     const int32_t* done;
     float* ctx;            // [R, hidden]

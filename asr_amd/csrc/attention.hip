@@ -167,6 +167,74 @@ __device__ __forceinline__ float exp_neg(float x)
     return (x == -INFINITY) ? 0.0f : fmaf(p, e * 6.93147182e-01f, p);
 }
 
+
+// ---- K/V storage of the decode-time attention kernels ---------------------------------------------------------
+// KV16 = false: float32 rows (every float32 precision mode).  KV16 = true (`precision: bf16` only): the caches hold bf16
+// (round to nearest even when a row is written), half the bytes of the HBM-bound key loop; scores, soft-max and P.V stay
+// in float32 on the exact-f32 MFMA, bf16 values are widened exactly.  A lane's 16 K values of one key are, in both
+// modes, 16-byte loads: float32 4 x (4 consecutive d at 16 q + 4 g), bf16 2 x (8 consecutive d at 32 (q / 2) + 8 g);
+// the MFMA's k index is only a summation label, so q fragments simply follow the same order (kv_d_of).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+template <bool KV16> __device__ __forceinline__ int kv_d_of(int q, int g)      // first of the 4 consecutive d of fragment q (0..3)
+{
+    return KV16 ? 32 * (q >> 1) + 8 * g + 4 * (q & 1) : 16 * q + 4 * g;
+}
+__device__ __forceinline__ f32x4 bf16_lo_hi(uint32_t w0, uint32_t w1)           // 4 bf16 in two words -> 4 floats
+{
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, w0 << 16); r[1] = __builtin_bit_cast(float, w0 & 0xffff0000u);
+    r[2] = __builtin_bit_cast(float, w1 << 16); r[3] = __builtin_bit_cast(float, w1 & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ u32x2_t f32x4_to_bf16(f32x4 x)                       // round to nearest even (v_cvt_pk_bf16_f32)
+{
+    return __builtin_bit_cast(u32x2_t, __builtin_convertvector(x, bf16x4_t));
+}
+__device__ __forceinline__ f32x4 bf16_round(f32x4 x)
+{
+    const u32x2_t b = f32x4_to_bf16(x);
+    return bf16_lo_hi(b[0], b[1]);
+}
+// registers a key block waits in between its loads and its MFMAs
+template <bool KV16> struct KvRegs;
+template <> struct KvRegs<false> { f32x4 k[4]; f32x4 v[4]; };
+template <> struct KvRegs<true> { u32x4_t k[2]; u32x2_t v[4]; };
+template <bool KV16> __device__ __forceinline__ void kv_load(KvRegs<KV16>& r, const void* kbase, size_t krow_elem, const void* vbase,
+                                                             const size_t (&vrow_elem)[4], int g, int c)
+{
+    // krow_elem / vrow_elem: element index of the row's d = 0 inside the cache
+    if constexpr (KV16) {
+        const uint16_t* kp = static_cast<const uint16_t*>(kbase) + krow_elem + 8 * g;
+        r.k[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kp));
+        r.k[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kp + 32));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            r.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(static_cast<const uint16_t*>(vbase) + vrow_elem[i] + 4 * c));
+    } else {
+        const float* kp = static_cast<const float*>(kbase) + krow_elem + 4 * g;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) r.k[db] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kp + db * 16));   // streamed once per step
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            r.v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(static_cast<const float*>(vbase) + vrow_elem[i] + 4 * c));
+    }
+}
+template <bool KV16> __device__ __forceinline__ void kv_unpack(const KvRegs<KV16>& r, f32x4 (&kc4)[4], f32x4 (&vc4)[4])
+{
+    if constexpr (KV16) {
+        kc4[0] = bf16_lo_hi(r.k[0][0], r.k[0][1]); kc4[1] = bf16_lo_hi(r.k[0][2], r.k[0][3]);
+        kc4[2] = bf16_lo_hi(r.k[1][0], r.k[1][1]); kc4[3] = bf16_lo_hi(r.k[1][2], r.k[1][3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vc4[i] = bf16_lo_hi(r.v[i][0], r.v[i][1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { kc4[i] = r.k[i]; vc4[i] = r.v[i]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Decoder self-attention at position `pos` (model.py:588-600 with reserve_last; no mask).
 // One workgroup per (utterance, head) serves all beams.  The beams' own k/v of position `pos` are
@@ -178,7 +246,7 @@ __device__ __forceinline__ float exp_neg(float x)
 // key is not on that beam's ancestry are masked to -inf.  HBM traffic = live rows, not beams x pos.
 // The new position's K keys (one per beam, valid for that beam only) are taken from LDS.
 // ------------------------------------------------------------------------------------------------
-template <int NB>
+template <int NB, bool KV16>
 __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArgs a)
 {
     if (*a.done) return;
@@ -218,8 +286,17 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
             v4 += *reinterpret_cast<const f32x4*>(bp + 2 * hidden);
             q4 = q4 * 0.125f;
             const size_t off = ((((size_t)u * a.heads + h) * width + pos) * K + kb) * 64 + cc * 4;   // head-major cache
-            *reinterpret_cast<f32x4*>(a.kcache + off) = k4;
-            *reinterpret_cast<f32x4*>(a.vcache + off) = v4;
+            if constexpr (KV16) {
+                // the row is used as the cache will return it from the next step on: rounded once, here
+                const u32x2_t kb16 = f32x4_to_bf16(k4), vb16 = f32x4_to_bf16(v4);
+                *reinterpret_cast<u32x2_t*>(static_cast<uint16_t*>(a.kcache) + off) = kb16;
+                *reinterpret_cast<u32x2_t*>(static_cast<uint16_t*>(a.vcache) + off) = vb16;
+                k4 = bf16_lo_hi(kb16[0], kb16[1]);
+                v4 = bf16_lo_hi(vb16[0], vb16[1]);
+            } else {
+                *reinterpret_cast<f32x4*>(static_cast<float*>(a.kcache) + off) = k4;
+                *reinterpret_cast<f32x4*>(static_cast<float*>(a.vcache) + off) = v4;
+            }
         }
         reinterpret_cast<f32x4*>(qs)[kb * 16 + cc] = q4;
         reinterpret_cast<f32x4*>(knew)[kb * 16 + cc] = k4;
@@ -240,7 +317,7 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int db = 0; db < 4; ++db) qf[nb][db] = reinterpret_cast<const f32x4*>(qs)[(nb * 16 + c) * 16 + db * 4 + g];
+        for (int db = 0; db < 4; ++db) qf[nb][db] = *reinterpret_cast<const f32x4*>(qs + (nb * 16 + c) * 64 + kv_d_of<KV16>(db, g));
     float m_run[NB], l_run[NB];
     f32x4 o[NB][4];
 #pragma unroll
@@ -293,33 +370,38 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
     const int nblk = (n_live + 15) >> 4;
     const size_t head_base = ((size_t)u * a.heads + h) * width;   // rows of this (utterance, head): [position][slot][64]
     // two register sets, used alternately (no copies): the next block's loads fly under this block's MFMAs
-    f32x4 kf[2][4], vf[2][4];
+    KvRegs<KV16> kv[2];
     int ej[2][4], es[2][4];
     auto load_block = [&](auto setc, int blk) {
         constexpr int S = decltype(setc)::value;
         const int key0 = blk * 16;
         const int e = live[min(key0 + c, n_live - 1)];
-        const float* kr = a.kcache + ((head_base + (e >> 5)) * K + (e & 31)) * 64 + 4 * g;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) kf[S][db] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kr + db * 16));   // streamed once per step
+        size_t vrow[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int idx = key0 + 4 * g + r;
             const int er = live[min(idx, n_live - 1)];
-            vf[S][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.vcache + ((head_base + (er >> 5)) * K + (er & 31)) * 64 + 4 * c));
+            vrow[r] = ((head_base + (er >> 5)) * K + (er & 31)) * 64;
             ej[S][r] = er >> 5;
             es[S][r] = idx < n_live ? (er & 31) : -2;
         }
+        kv_load<KV16>(kv[S], a.kcache, ((head_base + (e >> 5)) * K + (e & 31)) * 64, a.vcache, vrow, g, c);
+    };
+    auto compute_set = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+        f32x4 kc4[4], vc4[4];
+        kv_unpack<KV16>(kv[S], kc4, vc4);
+        compute(kc4, vc4, ej[S], es[S]);
     };
     using sc0 = std::integral_constant<int, 0>;
     using sc1 = std::integral_constant<int, 1>;
     if (wave < nblk) load_block(sc0{}, wave);
     for (int blk = wave; blk < nblk; blk += 8) {
         if (blk + 4 < nblk) load_block(sc1{}, blk + 4);
-        compute(kf[0], vf[0], ej[0], es[0]);
+        compute_set(sc0{});
         if (blk + 4 >= nblk) break;
         if (blk + 8 < nblk) load_block(sc0{}, blk + 8);
-        compute(kf[1], vf[1], ej[1], es[1]);
+        compute_set(sc1{});
     }
     // ---- the new position: key = beam, from LDS
 #pragma unroll
@@ -328,7 +410,7 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
             f32x4 kc4[4], vc4[4];
             int cj[4], cs[4];
 #pragma unroll
-            for (int db = 0; db < 4; ++db) kc4[db] = reinterpret_cast<const f32x4*>(knew)[(sb * 16 + c) * 16 + db * 4 + g];
+            for (int db = 0; db < 4; ++db) kc4[db] = *reinterpret_cast<const f32x4*>(knew + (sb * 16 + c) * 64 + kv_d_of<KV16>(db, g));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kbm = sb * 16 + 4 * g + r;
@@ -386,7 +468,7 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
 // Mask: -1e9 on padded encoder positions exactly as the reference (common_attention.py:202); keys
 // beyond t (block padding) get -inf.
 // ------------------------------------------------------------------------------------------------
-template <int NB>
+template <int NB, bool KV16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3 : 2)))
 void decoder_cross_attention_kernel(CrossAttnArgs a)
 {
@@ -402,8 +484,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
     // of a block is (per-lane base + block offset) + an immediate: no per-load address arithmetic.  The last block may run
     // past row t - 1: the engine allocates ASR_XATT_SLACK_ROWS spare rows behind K, V and the padding flags, and those keys
     // get -inf below.
-    const float* kptr = a.kc + ((size_t)u * a.heads + h) * t * 64 + c * 64 + 4 * g;      // key c, d = 4g .. (+ 16 db)
-    const float* vptr = a.v + ((size_t)u * a.heads + h) * t * 64 + (4 * g) * 64 + 4 * c; // key 4g (+ r), d = 4c ..
+    const size_t kv_base = ((size_t)u * a.heads + h) * t * 64;                            // element index of key 0, d 0
     const int32_t* pptr = a.pad2 + (size_t)u * t + 4 * g;                                 // key 4g (+ r)
     float m_run[NB], l_run[NB];
     f32x4 o[NB][4];
@@ -417,23 +498,22 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
     f32x4 qf[NB][4], qb[4];                                     // filled below, after the first block's loads are issued
     const int nblk = (t + 15) >> 4;
     // two register sets, used alternately (no copies): the next block's loads fly under this block's MFMAs
-    f32x4 kf[2][4], vf[2][4];
+    KvRegs<KV16> kv[2];
     int32_t padv[2][4];
     auto load_block = [&](auto setc, int blk) {
         constexpr int S = decltype(setc)::value;
-        const float* kr = kptr + (size_t)blk * 1024;
-        const float* vr = vptr + (size_t)blk * 1024;
+        const size_t row0 = kv_base + (size_t)blk * 1024;                                  // key blk * 16
+        const size_t vrow[4] = {row0 + (size_t)(4 * g) * 64, row0 + (size_t)(4 * g + 1) * 64, row0 + (size_t)(4 * g + 2) * 64,
+                                row0 + (size_t)(4 * g + 3) * 64};
+        kv_load<KV16>(kv[S], a.kc, row0 + (size_t)c * 64, a.v, vrow, g, c);                // streamed once: kept out of the caches
         const int32_t* pr = pptr + blk * 16;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) kf[S][db] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kr + db * 16));   // streamed once: keep it out of the caches
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            vf[S][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vr + r * 64));
-            padv[S][r] = pr[r];
-        }
+        for (int r = 0; r < 4; ++r) padv[S][r] = pr[r];
     };
     auto compute_block = [&](auto setc, int blk) {
         constexpr int S = decltype(setc)::value;
+        f32x4 kc4[4], vc4[4];
+        kv_unpack<KV16>(kv[S], kc4, vc4);
         float bc[4];
         const int keyq = blk * 16 + 4 * g;
 #pragma unroll
@@ -442,10 +522,10 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
             // spare rows past t hold whatever was there (possibly NaN): an -inf score alone would leave 0 x NaN in P.V
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (keyq + i >= t) vf[S][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (keyq + i >= t) vc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (blk * 16 + c >= t) {
 #pragma unroll
-                for (int db = 0; db < 4; ++db) kf[S][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int db = 0; db < 4; ++db) kc4[db] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
@@ -454,7 +534,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
 #pragma unroll
             for (int db = 0; db < 4; ++db)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[S][db][j], qf[nb][db][j], s, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc4[db][j], qf[nb][db][j], s, 0, 0, 0);
             // s[r] = S[beam nb*16+c][key key0 + 4g + r]
             float mx = -INFINITY;
 #pragma unroll
@@ -473,7 +553,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[S][r][j], s[r], o[nb][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc4[r][j], s[r], o[nb][j], 0, 0, 0);
         }
     };
     using xc0 = std::integral_constant<int, 0>;
@@ -482,11 +562,11 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
 
     // q fragments: split-K slabs fetched two at a time (independent loads in flight), summed in slab order
 #pragma unroll
-    for (int db = 0; db < 4; ++db) qb[db] = *reinterpret_cast<const f32x4*>(a.qbias + h * 64 + db * 16 + 4 * g);
+    for (int db = 0; db < 4; ++db) qb[db] = *reinterpret_cast<const f32x4*>(a.qbias + h * 64 + kv_d_of<KV16>(db, g));
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int beam = min(nb * 16 + c, K - 1);
-        const size_t off = (size_t)(u * K + beam) * hidden + h * 64 + 4 * g;
+        const size_t off = (size_t)(u * K + beam) * hidden + h * 64;
         f32x4 acc4[4];
 #pragma unroll
         for (int db = 0; db < 4; ++db) acc4[db] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -496,7 +576,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
             for (int j = 0; j < 2; ++j) {
                 const float* src = a.qpart + (size_t)min(z0 + j, a.nsplit - 1) * a.split_stride + off;
 #pragma unroll
-                for (int db = 0; db < 4; ++db) t4[j][db] = *reinterpret_cast<const f32x4*>(src + db * 16);
+                for (int db = 0; db < 4; ++db) t4[j][db] = *reinterpret_cast<const f32x4*>(src + kv_d_of<KV16>(db, g));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -580,10 +660,10 @@ size_t self_attention_lds_bytes(int k, int lds_stride)
     return (size_t)3 * nb * 16 * 64 * sizeof(float) + (lists > merge ? lists : merge);
 }
 
-template <int NB>
+template <int NB, bool KV16>
 hipError_t launch_self(const SelfAttnArgs& a, size_t lds, hipStream_t s)
 {
-    auto kern = decoder_self_attention_kernel<NB>;
+    auto kern = decoder_self_attention_kernel<NB, KV16>;
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -603,14 +683,20 @@ hipError_t launch_decoder_self_attention(const SelfAttnArgs& a, hipStream_t s)
     const size_t lds = self_attention_lds_bytes(a.k, a.lds_stride);
     if (lds > 150 * 1024 || a.k > ASR_MAX_BEAM || a.lds_stride > a.width || a.lds_stride < 2 || !a.live || !a.live_cnt)
         return hipErrorInvalidValue;
-    return a.k <= 16 ? launch_self<1>(a, lds, s) : launch_self<2>(a, lds, s);
+    if (a.kv_bf16) return a.k <= 16 ? launch_self<1, true>(a, lds, s) : launch_self<2, true>(a, lds, s);
+    return a.k <= 16 ? launch_self<1, false>(a, lds, s) : launch_self<2, false>(a, lds, s);
 }
 
 hipError_t launch_decoder_cross_attention(const CrossAttnArgs& a, hipStream_t s)
 {
     if (a.b <= 0) return hipSuccess;
     if (a.k > ASR_MAX_BEAM || a.k < 1 || a.t < 1) return hipErrorInvalidValue;
-    if (a.k <= 16) hipLaunchKernelGGL(decoder_cross_attention_kernel<1>, dim3(a.heads, a.b), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(decoder_cross_attention_kernel<2>, dim3(a.heads, a.b), dim3(256), 0, s, a);
+    if (a.kv_bf16) {
+        if (a.k <= 16) hipLaunchKernelGGL((decoder_cross_attention_kernel<1, true>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((decoder_cross_attention_kernel<2, true>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+    } else {
+        if (a.k <= 16) hipLaunchKernelGGL((decoder_cross_attention_kernel<1, false>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((decoder_cross_attention_kernel<2, false>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }

@@ -63,6 +63,7 @@ struct asr_handle {
     int32_t* range_flag = nullptr;      // device: set by an fp16x3 GEMM that met an activation outside fp16's range
     int64_t range_retries = 0;          // calls repeated on the bf16x6 kernels so far
     bool weights_out_of_range = false;  // single-kernel probes: the caller's weight operand did not fit fp16
+    bool kv_bf16 = false;               // precision bf16: K/V caches (self and cross) stored as bf16 (attention.hip KV16)
     int logit_split = 1;                // K slices of the logits GEMM (their slabs are summed by the top-k kernel)
     float* emb_gemm = nullptr;          // logits operand when tied: = emb (f32 mode) or its bf16 planes
     hipStream_t stream = nullptr;
@@ -422,8 +423,9 @@ int ensure_encoder_capacity(asr_handle* h, int n, int t)
     rc |= dev_alloc_t(h, &h->pad2, nrows + ASR_XATT_SLACK_ROWS);
     rc |= dev_alloc_t(h, &h->norm_scratch, input_norm_scratch_doubles(nn, 0, 0));
     for (int l = 0; l < h->L && !rc; ++l) {
-        rc |= dev_alloc_t(h, &h->cross_k[l], nrows * H + ASR_XATT_SLACK_ROWS * 64);
-        rc |= dev_alloc_t(h, &h->cross_v[l], nrows * H + ASR_XATT_SLACK_ROWS * 64);
+        const size_t kv_floats = (nrows * H + ASR_XATT_SLACK_ROWS * 64) / (h->kv_bf16 ? 2 : 1);      // bf16: two values a float
+        rc |= dev_alloc_t(h, &h->cross_k[l], kv_floats);
+        rc |= dev_alloc_t(h, &h->cross_v[l], kv_floats);
     }
     if (rc) return ASR_ERR_HIP;
     h->cap_rows = nrows; h->cap_n = nn;
@@ -473,8 +475,8 @@ int ensure_decoder_capacity(asr_handle* h, int n)
     rc |= dev_alloc_t(h, &h->cand_scores, R * (size_t)h->K);
     rc |= dev_alloc_t(h, &h->cand_tokens, R * (size_t)h->K);
     for (int l = 0; l < h->L && !rc; ++l) {
-        rc |= dev_alloc_t(h, &h->kcache[l], R * width * H);
-        rc |= dev_alloc_t(h, &h->vcache[l], R * width * H);
+        rc |= dev_alloc_t(h, &h->kcache[l], R * width * H / (h->kv_bf16 ? 2 : 1));
+        rc |= dev_alloc_t(h, &h->vcache[l], R * width * H / (h->kv_bf16 ? 2 : 1));
     }
     for (int i = 0; i < 2 && !rc; ++i) {
         rc |= dev_alloc_t(h, &h->beam.scores[i], R);
@@ -549,7 +551,7 @@ int run_cross_kv(asr_handle* h, int n, int t)
         int rc = gemm(h, h->x0, h->dec[l].wkv, h->dec[l].bkv, h->qkv, M, 2 * H, H, EPI_BIAS, 1);   // utils.py:618
         if (rc) return rc;
         ProfScope ps(h, "pack_cross_kv", 0, 4.0 * M * 4.0 * H);
-        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, h->heads, h->cross_k[l], h->cross_v[l], h->stream));
+        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, h->heads, h->cross_k[l], h->cross_v[l], h->kv_bf16 ? 1 : 0, h->stream));
     }
     return ASR_OK;
 }
@@ -631,7 +633,9 @@ int step_attention_half(asr_handle* h, const DecView& v, const StepCtx& c, int l
     {
         SelfAttnArgs a{};
         a.qkv = v.part; a.nsplit = c.s_qkv; a.split_stride = 3 * RH; a.bias = b.bqkv;
-        a.kcache = h->kcache[l] + v.cache_off; a.vcache = h->vcache[l] + v.cache_off;
+        const size_t esz = h->kv_bf16 ? 2 : 4;                       // bytes per cached value
+        a.kcache = reinterpret_cast<char*>(h->kcache[l]) + v.cache_off * esz; a.vcache = reinterpret_cast<char*>(h->vcache[l]) + v.cache_off * esz;
+        a.kv_bf16 = h->kv_bf16 ? 1 : 0;
         a.anc0 = st.anc[0]; a.anc1 = st.anc[1]; a.live = st.live; a.live_cnt = st.live_cnt; a.pos = st.pos; a.done = st.done;
         a.ctx = v.dctx; a.b = n; a.k = K; a.heads = h->heads; a.width = st.width;
         a.lds_stride = std::min(st.width, st.limit + 2);
@@ -650,9 +654,12 @@ int step_attention_half(asr_handle* h, const DecView& v, const StepCtx& c, int l
     {
         CrossAttnArgs a{};
         a.qpart = v.part; a.nsplit = c.s_proj; a.split_stride = RH; a.qbias = b.bq;
-        a.kc = h->cross_k[l] + v.cross_off; a.v = h->cross_v[l] + v.cross_off; a.pad2 = v.pad2; a.done = st.done;
+        const size_t esz = h->kv_bf16 ? 2 : 4;
+        a.kc = reinterpret_cast<const char*>(h->cross_k[l]) + v.cross_off * esz; a.v = reinterpret_cast<const char*>(h->cross_v[l]) + v.cross_off * esz;
+        a.kv_bf16 = h->kv_bf16 ? 1 : 0;
+        a.pad2 = v.pad2; a.done = st.done;
         a.ctx = v.dctx; a.b = n; a.k = K; a.heads = h->heads; a.t = t;
-        ProfScope ps(h, "decoder_cross_attention", 4.0 * R * (double)t * H, 4.0 * 2.0 * n * (double)t * H, s);
+        ProfScope ps(h, "decoder_cross_attention", 4.0 * R * (double)t * H, (h->kv_bf16 ? 2.0 : 4.0) * 2.0 * n * (double)t * H, s);
         HIP_TRY(h, launch_decoder_cross_attention(a, s));
     }
     rc = gemm(h, v.dctx, b.wco, nullptr, v.part, R, H, H, EPI_PARTIAL, c.s_proj, s);
@@ -965,6 +972,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     h->nprod = cfg->precision == ASR_PRECISION_F32_BF16X6 ? 6 : cfg->precision == ASR_PRECISION_BF16X3 ? 3
              : cfg->precision == ASR_PRECISION_BF16 ? 1 : cfg->precision == ASR_PRECISION_F32_F16X3 ? 13 : 0;
     h->nprod_active = h->nprod;
+    h->kv_bf16 = cfg->precision == ASR_PRECISION_BF16;
     switch (cfg->ff_activation) {
         case ASR_FF_SIGMOID: h->ff_epi = EPI_SIGMOID; break;
         case ASR_FF_TANH: h->ff_epi = EPI_TANH; break;

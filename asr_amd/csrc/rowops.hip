@@ -349,9 +349,12 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
 
 // ---- cross-attention K/V layouts: kv [n*t][2H] -> k, v [n][heads][t][64] (head-major, so that one
 // (utterance, head) workgroup of the decode-time cross-attention streams two contiguous arrays) ----
+template <bool KV16>
 __global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restrict__ kv, int t, int heads,
-                                                             float* __restrict__ kout, float* __restrict__ vout)
+                                                             void* __restrict__ kout, void* __restrict__ vout)
 {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     const int t0 = blockIdx.x * 64, h = blockIdx.y, u = blockIdx.z;
     const int hidden = heads * 64;
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
@@ -359,8 +362,14 @@ __global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restr
         if (t0 + tt < t) {
             const float* row = kv + ((size_t)u * t + t0 + tt) * (2 * hidden);
             const size_t o = (((size_t)u * heads + h) * t + t0 + tt) * 64;
-            reinterpret_cast<f32x4*>(kout + o)[c] = reinterpret_cast<const f32x4*>(row + h * 64)[c];
-            reinterpret_cast<f32x4*>(vout + o)[c] = reinterpret_cast<const f32x4*>(row + hidden + h * 64)[c];
+            const f32x4 k4 = reinterpret_cast<const f32x4*>(row + h * 64)[c], v4 = reinterpret_cast<const f32x4*>(row + hidden + h * 64)[c];
+            if constexpr (KV16) {
+                reinterpret_cast<u32x2_t*>(static_cast<uint16_t*>(kout) + o)[c] = __builtin_bit_cast(u32x2_t, __builtin_convertvector(k4, bf16x4_t));
+                reinterpret_cast<u32x2_t*>(static_cast<uint16_t*>(vout) + o)[c] = __builtin_bit_cast(u32x2_t, __builtin_convertvector(v4, bf16x4_t));
+            } else {
+                reinterpret_cast<f32x4*>(static_cast<float*>(kout) + o)[c] = k4;
+                reinterpret_cast<f32x4*>(static_cast<float*>(vout) + o)[c] = v4;
+            }
         }
     }
 }
@@ -814,10 +823,11 @@ hipError_t launch_xent_rows(const float* logits, const int32_t* Y, int rows, int
     return hipGetLastError();
 }
 
-hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, float* k, float* v, hipStream_t s)
+hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, void* k, void* v, int kv_bf16, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_cross_kv_kernel, dim3((t + 63) / 64, heads, n), dim3(256), 0, s, kv, t, heads, k, v);
+    if (kv_bf16) hipLaunchKernelGGL(pack_cross_kv_kernel<true>, dim3((t + 63) / 64, heads, n), dim3(256), 0, s, kv, t, heads, k, v);
+    else hipLaunchKernelGGL(pack_cross_kv_kernel<false>, dim3((t + 63) / 64, heads, n), dim3(256), 0, s, kv, t, heads, k, v);
     return hipGetLastError();
 }
 

@@ -42,7 +42,9 @@ enum asr_ff_activation { ASR_FF_RELU = 0, ASR_FF_GLU = 1, ASR_FF_SIGMOID = 2, AS
  *               (terms below 2^-24 of the product dropped): f32-chain accuracy at 2.7x the matrix rate.  A layer
  *               whose input width is not a multiple of 32 runs on the F32 kernel in this and the next two modes.
  *   BF16X3      two terms each, three products (~2^-16 relative product error).
- *   BF16        operands rounded to bf16 (north_star's "bf16 MFMA" mode; tolerance stated in the tests).
+ *   BF16        operands rounded to bf16 (north_star's "bf16 MFMA" mode; tolerance stated in the tests).  This mode also
+ *               stores the decoder's K/V caches (self-attention history and the per-utterance cross-attention K/V) as
+ *               bf16: half the bytes of the HBM-bound attention loops; scores, soft-max and P.V stay float32.
  *   F32_F16X3   float32 operands split as x = x1 + 2^-11 x2 with x1 = fp16(x), x2 = fp16(2^11 (x - x1)) (11 + 11 significand
  *               bits); three fp16 matrix products per k-step, the 2^-11 group in an accumulator of its own: measured
  *               against float64 its error is below the exact-f32 kernel's, at 5.3x the f32 matrix rate.  fp16 holds

@@ -209,3 +209,38 @@ def test_bf16_mode_logits_within_stated_tolerance():
         assert Y.dtype == np.int32 and Y.shape[0] == X.shape[0]
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('beam,lens', [(3, (60, 90, 75)), (20, (45, 70))])
+def test_bf16_mode_with_bf16_kv_caches_follows_the_oracle_over_several_steps(beam, lens):
+    """`precision: bf16` also stores the self- and cross-attention K/V caches as bf16 (attention.hip KV16: half the bytes of
+    the HBM-bound key loops; scores, soft-max and P.V stay float32).  Tolerance as for the mode: logits 5e-2 (max-abs /
+    max-abs) against the float64 oracle for as long as the GPU's beam follows the oracle's; the history rows are read back
+    from the bf16 cache from step 2 on, beam 20 runs the two-beam-group kernels.  Deterministic, and the two-stream split
+    gives the same hypotheses."""
+    ocfg = tiny_config(beam_size=beam, max_target_length=11)
+    W = O.random_weights(ocfg, seed=3, bias_scale=0.1)
+    X = tiny_inputs(lens, seed=13)
+    from asr_amd.model import Engine
+    eng = _engine(ocfg, 'bf16', W)
+    two = Engine(product_config(ocfg, precision='bf16', sub_batches=2), 0)
+    two.load_weights(W)
+    try:
+        Wc = O.cast_weights(W, np.float64)
+        enc64, _ = O.encoder(X.astype(np.float64), Wc, ocfg)
+        trace = {}
+        want = O.beam_search(enc64, Wc, ocfg, algo='kv', trace=trace)
+        Y, tr = eng.decode_trace(X, want.shape[1])
+        followed = 0
+        for s in range(want.shape[1]):
+            assert rel_err(tr['logits'][s], trace['logits'][s]) < 5e-2, 'step %d' % s
+            followed += 1
+            if not (np.array_equal(tr['tokens'][s], trace['tokens'][s]) and np.array_equal(tr['parents'][s], trace['parents'][s])):
+                break
+        assert followed >= 2, 'the case must reach a step that reads history rows from the bf16 cache'
+        assert np.array_equal(eng.decode(X), Y)
+        assert np.array_equal(two.decode(X), Y)
+        assert eng.device_bytes() > 0
+    finally:
+        eng.close()
+        two.close()
