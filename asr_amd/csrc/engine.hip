@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -110,6 +111,14 @@ struct asr_handle {
     std::vector<ProfClass> prof;
     double prof_overhead_ms = 0.0;     // elapsed time of an event pair with nothing between (calibrated by asr_set_profile)
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    // profile mode 2 (brackets left in the queue, no host wait per kernel: the durations kernels have in the running
+    // pipeline, the other sub-batch's kernels beside them): a pool of events and the brackets not yet read back
+    struct ProfPending { int cls; hipEvent_t e0, e1; };
+    std::vector<hipEvent_t> prof_free;
+    std::deque<ProfPending> prof_pending;
+    int32_t* live_host = nullptr;      // pinned [steps + 2][n]: live-row counts per step (what self-attention streamed)
+    size_t live_host_cap = 0;
+    int live_host_n = 0;
 };
 
 namespace {
@@ -153,33 +162,71 @@ int dev_alloc_t(asr_handle* h, T** p, size_t count)
 }
 
 // ---- profile brackets -----------------------------------------------------------------------
+hipEvent_t prof_event(asr_handle* h)
+{
+    hipEvent_t e = nullptr;
+    if (!h->prof_free.empty()) { e = h->prof_free.back(); h->prof_free.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e;
+}
+
+// reads back the brackets of profile mode 2 in launch order; wait = false stops at the first one still in flight
+void prof_drain(asr_handle* h, bool wait)
+{
+    while (!h->prof_pending.empty()) {
+        const asr_handle::ProfPending p = h->prof_pending.front();
+        if (wait) (void)hipEventSynchronize(p.e1);
+        else if (hipEventQuery(p.e1) != hipSuccess) break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess && p.cls < (int)h->prof.size())
+            h->prof[p.cls].ms += std::max(0.0, (double)ms - h->prof_overhead_ms);
+        h->prof_free.push_back(p.e0);
+        h->prof_free.push_back(p.e1);
+        h->prof_pending.pop_front();
+    }
+}
+
 struct ProfScope {
     asr_handle* h;
-    ProfClass* pc = nullptr;
+    int cls = -1;
     hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     // `stream` = the stream the bracketed kernel is launched on (a half batch's kernels run on their own stream)
     ProfScope(asr_handle* h_, const char* name, double flops, double bytes, hipStream_t stream = nullptr) : h(h_), st(stream ? stream : h_->stream)
     {
         if (!h->profile) return;
-        for (auto& c : h->prof)
-            if (c.name == name || strcmp(c.name, name) == 0) { pc = &c; break; }
-        if (!pc) {
+        for (size_t i = 0; i < h->prof.size(); ++i)
+            if (h->prof[i].name == name || strcmp(h->prof[i].name, name) == 0) { cls = (int)i; break; }
+        if (cls < 0) {
             h->prof.push_back(ProfClass{name});
-            pc = &h->prof.back();
+            cls = (int)h->prof.size() - 1;
         }
-        pc->flops += flops;
-        pc->bytes += bytes;
-        pc->launches += 1;
-        (void)hipEventRecord(h->pe0, st);
+        ProfClass& pc = h->prof[cls];
+        pc.flops += flops;
+        pc.bytes += bytes;
+        pc.launches += 1;
+        if (h->profile == 2) {
+            e0 = prof_event(h); e1 = prof_event(h);
+            if (e0 && e1) (void)hipEventRecord(e0, st);
+        } else {
+            (void)hipEventRecord(h->pe0, st);
+        }
     }
     ~ProfScope()
     {
-        if (!pc) return;
+        if (cls < 0) return;
+        if (h->profile == 2) {
+            if (e0 && e1) {
+                (void)hipEventRecord(e1, st);
+                h->prof_pending.push_back(asr_handle::ProfPending{cls, e0, e1});
+            }
+            return;
+        }
         (void)hipEventRecord(h->pe1, st);
         (void)hipEventSynchronize(h->pe1);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, h->pe0, h->pe1);
-        pc->ms += std::max(0.0, (double)ms - h->prof_overhead_ms);    // minus what an EMPTY event pair measures
+        h->prof[cls].ms += std::max(0.0, (double)ms - h->prof_overhead_ms);    // minus what an EMPTY event pair measures
     }
 };
 
@@ -599,7 +646,7 @@ DecView make_view(asr_handle* h, int idx, int n0, int nv, int t, hipStream_t str
 // One decode step (model.py:270-303 with decoder_with_caching_impl :559-633 restated on a K/V cache), in pieces: head
 // (embedding), per block an attention half and a feed-forward half, tail (logits, soft-max/top-k, pruning).
 struct StepCtx {
-    int n, R, s_qkv, s_proj, s_ffn2;
+    int n, R, s_qkv, s_proj, s_ffn2, step;
     size_t RH;
 };
 
@@ -639,7 +686,9 @@ int step_attention_half(asr_handle* h, const DecView& v, const StepCtx& c, int l
         a.anc0 = st.anc[0]; a.anc1 = st.anc[1]; a.live = st.live; a.live_cnt = st.live_cnt; a.pos = st.pos; a.done = st.done;
         a.ctx = v.dctx; a.b = n; a.k = K; a.heads = h->heads; a.width = st.width;
         a.lds_stride = std::min(st.width, st.limit + 2);
-        ProfScope ps(h, "decoder_self_attention", 0, 0, s);
+        // bytes here: the q/k/v slabs in, the new K/V rows and the context out; the history it streams (the utterances'
+        // LIVE rows) is added by decode_core from the live counts of the steps that ran
+        ProfScope ps(h, "decoder_self_attention", 0, 4.0 * R * 3.0 * H * c.s_qkv + 2.0 * R * H * (double)esz + 4.0 * R * H, s);
         HIP_TRY(h, launch_decoder_self_attention(a, s));
     }
     rc = gemm(h, v.dctx, b.wo, nullptr, v.part, R, H, H, EPI_PARTIAL, c.s_proj, s);
@@ -702,7 +751,7 @@ int step_tail(asr_handle* h, const DecView& v, const StepCtx& c)
         HIP_TRY(h, launch_log_softmax_topk(v.logits, s_log, (size_t)R * h->V, R, h->V, K, v.cand_scores, v.cand_tokens, st.done, s));   // :345-346
     }
     {
-        ProfScope ps(h, "beam_step", 0, 0, s);
+        ProfScope ps(h, "beam_step", 0, 4.0 * R * H * 3.0, s);          // embedding row + timing row in, next decoder input out
         const float mult = h->cfg.scale_embedding ? (float)sqrt((double)h->H) : 1.0f;
         HIP_TRY(h, launch_beam_step(st, v.cand_scores, v.cand_tokens, c.n, K, h->emb, h->pe, mult, H, v.y0, s));   // :280-301, :569-576
     }
@@ -713,13 +762,17 @@ int step_tail(asr_handle* h, const DecView& v, const StepCtx& c)
 // (rocprofv3 kernel trace of both queues) is that two kernels that share the CUs each take about the sum of their solo
 // times - also an HBM-bound attention kernel beside a matrix-bound GEMM - so forcing the views half a block apart with
 // events (tried: -12 %) buys nothing; the gain of two views (+3.3 %) is the launch gaps and tails they fill for each other.
-int run_decode_step(asr_handle* h, DecView* views, const bool* active, int nviews, int t, bool first_step)
+int run_decode_step(asr_handle* h, DecView* views, const bool* active, int nviews, int t, int step)
 {
     for (int vi = 0; vi < nviews; ++vi) {
         if (!active[vi]) continue;
         const DecView& v = views[vi];
-        const StepCtx c = step_ctx(h, v);
-        int rc = first_step ? step_head(h, v, c) : ASR_OK;           // later steps: beam_step_kernel wrote the decoder input
+        StepCtx c = step_ctx(h, v);
+        c.step = step;
+        if (h->profile && h->live_host && (size_t)(step + 1) * h->live_host_n <= h->live_host_cap)
+            HIP_TRY(h, hipMemcpyAsync(h->live_host + (size_t)step * h->live_host_n + v.n0, v.beam.live_cnt, (size_t)v.n * sizeof(int32_t),
+                                      hipMemcpyDeviceToHost, v.stream));
+        int rc = step == 1 ? step_head(h, v, c) : ASR_OK;           // later steps: beam_step_kernel wrote the decoder input
         if (rc) return rc;
         for (int l = 0; l < h->L; ++l) {
             if ((rc = step_attention_half(h, v, c, l, t))) return rc;
@@ -768,6 +821,18 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     const int K = h->K, R = n * K;
     h->beam.limit = std::min(t + 50, (int)h->cfg.max_target_length);                                // :310 (Q7)
     const int max_steps = h->beam.limit + 1;
+    if (h->profile && !tr) {
+        const size_t need = (size_t)(max_steps + 2) * n;
+        if (need > h->live_host_cap) {
+            if (h->live_host) (void)hipHostFree(h->live_host);
+            h->live_host = nullptr; h->live_host_cap = 0;
+            HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->live_host), need * sizeof(int32_t), 0));
+            h->live_host_cap = need;
+        }
+        h->live_host_n = n;
+    } else {
+        h->live_host_n = 0;
+    }
     // Utterances are independent, so the search may run as two halves with their own loop state on two streams
     // (kernels of one half fill the launch gaps and tails of the other's).  The joint loop of the reference ends
     // when every utterance has finished: a half that ends earlier is padded with 3, which is what further steps
@@ -792,7 +857,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     for (int s = 1; s <= max_steps && !all_ended(); ++s) {
         bool active[MAX_VIEWS];
         for (int vi = 0; vi < MAX_VIEWS; ++vi) active[vi] = !ended[vi];
-        rc = run_decode_step(h, views, active, nviews, t, s == 1);
+        rc = run_decode_step(h, views, active, nviews, t, s);
         if (rc) return rc;
         if (tr && s <= tr->steps) {
             const int buf = s & 1;
@@ -826,6 +891,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
                 if (v.done_host[c]) ended[vi] = true;
             }
         }
+        if (h->profile == 2) prof_drain(h, false);
     }
     int lens[MAX_VIEWS] = {0, 0, 0, 0};
     for (int vi = 0; vi < nviews; ++vi) {
@@ -835,6 +901,18 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
         lens[vi] = posd[0];
         if (!posd[1] || lens[vi] < 1 || lens[vi] > max_steps)
             return fail(h, ASR_ERR_HIP, "beam search loop ended in an inconsistent state");
+    }
+    if (h->profile == 2) prof_drain(h, true);
+    if (h->profile && h->live_host_n == n) {                       // what self-attention streamed: the live rows of every step taken
+        double live = 0.0;
+        for (int vi = 0; vi < nviews; ++vi)
+            for (int s = 1; s <= lens[vi]; ++s)
+                for (int u = 0; u < views[vi].n; ++u) live += h->live_host[(size_t)s * n + views[vi].n0 + u];
+        for (auto& pc : h->prof)
+            if (strcmp(pc.name, "decoder_self_attention") == 0) {
+                pc.bytes += h->L * live * 2.0 * h->H * (h->kv_bf16 ? 2.0 : 4.0);
+                pc.flops += h->L * live * 4.0 * K * h->H;
+            }
     }
     const int len = *std::max_element(lens, lens + MAX_VIEWS);
     if ((int64_t)n * len > y_capacity) return fail(h, ASR_ERR_CAPACITY, "Y too small: need n * " + std::to_string(len) + " int32");
@@ -1030,6 +1108,9 @@ void asr_destroy(asr_handle* h)
     if (h->range_flag) (void)hipFree(h->range_flag);
     if (h->done_host) (void)hipHostFree(h->done_host);
     for (auto ev : h->step_events) if (ev) (void)hipEventDestroy(ev);
+    for (auto& p : h->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    for (hipEvent_t e : h->prof_free) (void)hipEventDestroy(e);
+    if (h->live_host) (void)hipHostFree(h->live_host);
     if (h->pe0) (void)hipEventDestroy(h->pe0);
     if (h->pe1) (void)hipEventDestroy(h->pe1);
     if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
@@ -1623,7 +1704,8 @@ int asr_op_beam_step(asr_handle* h, const float* scores, const int32_t* finished
 int asr_set_profile(asr_handle* h, int32_t mode)
 {
     if (!h) return ASR_ERR_ARG;
-    h->profile = mode ? 1 : 0;
+    if (h->profile == 2) prof_drain(h, true);
+    h->profile = mode == 2 ? 2 : mode ? 1 : 0;
     if (mode) {
         h->prof.clear();
         // An event pair brackets the kernel AND the completion signalling of its own two markers; calibrate that
@@ -1631,7 +1713,20 @@ int asr_set_profile(asr_handle* h, int32_t mode)
         int rc = set_device(h);
         if (rc) return rc;
         std::vector<float> v;
-        for (int i = 0; i < 33; ++i) {
+        if (h->profile == 2) {                                     // pairs queued back to back, as the brackets of this mode are
+            std::vector<hipEvent_t> ev;
+            for (int i = 0; i < 66; ++i) ev.push_back(prof_event(h));
+            for (hipEvent_t e : ev) if (!e) return fail(h, ASR_ERR_HIP, "hipEventCreate failed");
+            for (int i = 0; i < 66; ++i) HIP_TRY(h, hipEventRecord(ev[i], h->stream));
+            HIP_TRY(h, hipEventSynchronize(ev[65]));
+            for (int i = 0; i < 66; i += 2) {
+                float ms = 0.f;
+                HIP_TRY(h, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+                v.push_back(ms);
+            }
+            for (hipEvent_t e : ev) h->prof_free.push_back(e);
+        }
+        for (int i = 0; i < 33 && h->profile == 1; ++i) {
             HIP_TRY(h, hipEventRecord(h->pe0, h->stream));
             HIP_TRY(h, hipEventRecord(h->pe1, h->stream));
             HIP_TRY(h, hipEventSynchronize(h->pe1));
@@ -1649,6 +1744,7 @@ int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, 
                     int32_t* n_out)
 {
     if (!h || !n_out) return ASR_ERR_ARG;
+    if (h->profile == 2 && set_device(h) == ASR_OK) prof_drain(h, true);
     int n = std::min<int>(cap, (int)h->prof.size());
     int64_t total = 0;
     for (int i = 0; i < n; ++i) {

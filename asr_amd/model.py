@@ -218,7 +218,9 @@ class Engine(object):
 
     # ---- instrumentation ---------------------------------------------------------------------
     def set_profile(self, on):
-        _lib.check(self._h, lib.asr_set_profile(self._h, 1 if on else 0))
+        """False / 0: off; True / 1: every kernel bracketed and waited for (solo durations); 2: brackets left in the
+        queues (durations in the running pipeline, sub-batches side by side)."""
+        _lib.check(self._h, lib.asr_set_profile(self._h, int(on)))
 
     def get_profile(self):
         cap = 64

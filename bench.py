@@ -192,6 +192,7 @@ def roofline_of(prof, precision):
         r['mfma_products_per_multiply'] = nprod
         r['executed_frac'] = nprod * ach / peak
     kernels = [{'name': p['name'], 'ms': round(p['ms'], 3), 'launches': p['launches'],
+                'avg_us': round(1000.0 * p['ms'] / max(p['launches'], 1), 2),
                 'tflops': round(p['flops'] / (p['ms'] * 1e-3) / 1e12, 2) if p['ms'] > 0 else 0.0,
                 'gbs': round(p['bytes'] / (p['ms'] * 1e-3) / 1e9, 1) if p['ms'] > 0 else 0.0}
                for p in sorted(prof, key=lambda p: -p['ms'])]
@@ -396,13 +397,22 @@ def main():
                        # fp16's range (0 = every timed step ran on the fp16x3 kernels)
                        'range_retries': eng.range_retries()},
         }
-        # ---- roofline of the dominant kernel: HIP events around every launch of one extra pass (the same half batches
-        # as the timed passes; the brackets serialise the host, so the two halves do not overlap in this pass) ----
-        eng.set_profile(True)
+        # ---- roofline of the dominant kernel: HIP events around every launch of one extra pass, on the stream each
+        # kernel is launched on, left in the queues and read back afterwards (profile mode 2): the same sub-batches side
+        # by side as in the timed passes, i.e. the durations rocprofv3 --kernel-trace reports for this command.  A second
+        # pass waits for every bracket (mode 1): each kernel alone on the GPU, reported as `solo_us` ----
+        eng.set_profile(2)
         eng.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
         prof = eng.get_profile()
-        eng.set_profile(False)
+        eng.set_profile(1)
+        eng.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
+        solo = {p['name']: p for p in eng.get_profile()}
+        eng.set_profile(0)
         out['roofline'], out['kernels'] = roofline_of(prof, args.precision)
+        for k in out['kernels']:
+            p1 = solo.get(k['name'])
+            if p1 and p1['launches']:
+                k['solo_us'] = round(1000.0 * p1['ms'] / p1['launches'], 2)
         if world == 1 and not args.no_cpu_baseline:
             cb, Yc = cpu_baseline(cfg, W, raw, min(args.cpu_sample_utts, n))
             m = min(Yc.shape[1], Y.shape[1])

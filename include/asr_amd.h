@@ -205,12 +205,14 @@ int asr_op_beam_step(asr_handle* h, const float* scores, const int32_t* finished
 /* ---- instrumentation ---------------------------------------------------------------------- */
 
 /* mode 0: normal.  mode 1: bracket every kernel launch of subsequent calls with HIP events on the
- * handle's stream and accumulate per-kernel-class time (serialises the host; for bench.py's
- * roofline leg and nothing else). */
+ * stream it is launched on and accumulate per-kernel-class time; the host waits for every bracket, so each
+ * kernel runs alone (its solo duration).  mode 2: the same brackets left in the queues and read back
+ * afterwards: the durations kernels have in the running pipeline, with the other sub-batches' kernels beside
+ * them (what rocprofv3 --kernel-trace sees; bench.py's roofline leg).  For measurement and nothing else. */
 int asr_set_profile(asr_handle* h, int32_t mode);
-/* Returns up to `cap` classes accumulated since the last asr_set_profile(h, 1):
+/* Returns up to `cap` classes accumulated since the last asr_set_profile(h, 1 or 2):
  * names[i] (static strings), total milliseconds, launch counts, algorithmic FLOPs and bytes.
- * asr_set_profile(h, 1) times an EMPTY event pair (median of 33) and that figure is subtracted from every
+ * asr_set_profile times an EMPTY event pair (median of 33, issued the way the mode issues its brackets) and that figure is subtracted from every
  * bracket; the total subtracted is returned as the last class, named "(event_pair_overhead)". */
 int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, int64_t* launches,
                     double* flops, double* bytes, int32_t* n_out);

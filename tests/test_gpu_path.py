@@ -141,6 +141,41 @@ def test_two_half_batches_on_two_streams_give_the_same_hypotheses(lens, beam, mt
         two.close()
 
 
+def test_profile_modes_bracket_every_launch_and_leave_the_hypotheses_alone():
+    """asr_set_profile 1 (every bracket waited for) and 2 (brackets left in the two queues): the same classes and launch
+    counts, times > 0, the same hypotheses as an unprofiled call; self-attention's bytes are the live rows streamed."""
+    ocfg = tiny_config(beam_size=4, max_target_length=14)
+    W = O.random_weights(ocfg, seed=31, bias_scale=0.1)
+    X = tiny_inputs((75, 40, 90, 33, 60, 81), seed=32)
+    eng = _engine(ocfg, W, sub_batches=2)
+    try:
+        want = eng.decode(X)
+        profs = {}
+        for mode in (1, 2, 1, 2):
+            eng.set_profile(mode)
+            assert np.array_equal(eng.decode(X), want)
+            profs[mode] = {p['name']: p for p in eng.get_profile()}
+            eng.set_profile(0)
+        assert set(profs[1]) == set(profs[2])
+        for name, p in profs[2].items():
+            assert p['launches'] == profs[1][name]['launches'], name
+            assert p['flops'] == profs[1][name]['flops'] and p['bytes'] == profs[1][name]['bytes'], name
+            if not name.startswith('('):
+                assert 0.0 < p['ms'] < 1000.0 and 0.0 < profs[1][name]['ms'] < 1000.0, name
+        steps = want.shape[1]
+        sa = profs[2]['decoder_self_attention']
+        assert sa['launches'] == 2 * steps * ocfg['num_blocks']
+        # what it streams lies between 1 live row per history position (all beams share one history) and beam_size
+        H, L, R = ocfg['hidden_units'], ocfg['num_blocks'], len(X) * ocfg['beam_size']
+        fixed = lambda sq: steps * L * (4.0 * R * 3 * H * sq + 2.0 * R * H * 4 + 4.0 * R * H)     # slabs in, new K/V + context out
+        hist = sum(len(X) * s for s in range(steps)) * L * 2.0 * H * 4
+        assert sa['flops'] > 0
+        assert fixed(1) + 0.5 * hist <= sa['bytes'] <= fixed(8) + hist * ocfg['beam_size']
+        assert np.array_equal(eng.decode(X), want)
+    finally:
+        eng.close()
+
+
 def test_device_front_end_matches_host_stacking():
     """asr_decode_dev with raw fbank == stacking on the host first (uniform lengths)."""
     import torch
