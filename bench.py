@@ -438,9 +438,13 @@ def main():
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - ta) / max(args.alt_steps, 1)
                 m = min(Ya.shape[1], Y.shape[1])
+                same = np.all(Ya[:, :m] == Y[:, :m], axis=1)
                 alts[prec] = {'value': n * t_raw / 100.0 / dt, 'unit': 'audio-sec/sec', 'ms_per_step': 1000.0 * dt,
                               'steps': args.alt_steps, 'dtype': PRECISION_INFO[prec][0].split(' (')[0],
-                              'hypotheses_match': bool(Ya.shape == Y.shape and np.array_equal(Ya[:, :m], Y[:, :m]))}
+                              # against the default mode's hypotheses on this batch: random-init weights over 201 steps
+                              # leave near-ties, so one f32-rounding-level difference can turn an utterance's beam
+                              'hypotheses_match': bool(Ya.shape == Y.shape and same.all()),
+                              'utterances_identical': '%d of %d' % (int(same.sum()), n)}
                 e2.close()
             out['alt_precisions'] = alts
         print(json.dumps(out), flush=True)
