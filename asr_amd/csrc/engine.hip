@@ -104,6 +104,7 @@ struct asr_handle {
     // so that the launch gaps and tails of one half's kernels are filled by the other's (ASR_AMD_SUBBATCH=1 disables)
     hipStream_t xstream[3] = {nullptr, nullptr, nullptr};   // streams of sub-batches 1..3 (sub-batch 0 runs on `stream`)
     hipEvent_t fork_ev = nullptr;
+    bool use_graph = false;             // steps 2.. of the beam search replayed from a captured HIP graph (ASR_AMD_GRAPH)
     int sub_batches = 0;                // 0 = automatic (two halves from 320 rows), 1 = never, 2..4 = that many parts whenever n allows
 
     // profile
@@ -758,27 +759,65 @@ int step_tail(asr_handle* h, const DecView& v, const StepCtx& c)
     return ASR_OK;
 }
 
+int run_view_step(asr_handle* h, const DecView& v, int t, int step)
+{
+    StepCtx c = step_ctx(h, v);
+    c.step = step;
+    if (h->profile && h->live_host && (size_t)(step + 1) * h->live_host_n <= h->live_host_cap)
+        HIP_TRY(h, hipMemcpyAsync(h->live_host + (size_t)step * h->live_host_n + v.n0, v.beam.live_cnt, (size_t)v.n * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, v.stream));
+    int rc = step == 1 ? step_head(h, v, c) : ASR_OK;               // later steps: beam_step_kernel wrote the decoder input
+    if (rc) return rc;
+    for (int l = 0; l < h->L; ++l) {
+        if ((rc = step_attention_half(h, v, c, l, t))) return rc;
+        if ((rc = step_ffn_half(h, v, c, l))) return rc;
+    }
+    return step_tail(h, v, c);
+}
+
+// Steps 2.. of a view launch the same kernels with the same arguments (the step index, the double-buffer parity and the
+// loop state live on the device), so the step is captured once per call into a HIP graph and replayed: one host call
+// per step and view instead of 70, and the queue holds the whole step when its first kernel starts.
+int capture_view_step(asr_handle* h, const DecView& v, int t, hipGraphExec_t* out)
+{
+    HIP_TRY(h, hipStreamBeginCapture(v.stream, hipStreamCaptureModeThreadLocal));
+    const int rc = run_view_step(h, v, t, 2);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(v.stream, &g);
+    if (rc || e != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc ? rc : fail(h, ASR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    }
+    const hipError_t e2 = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e2 != hipSuccess) return fail(h, ASR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e2));
+    return ASR_OK;
+}
+
+struct StepGraphs {                                                  // one per view, destroyed when the call returns
+    hipGraphExec_t g[MAX_VIEWS] = {nullptr, nullptr, nullptr, nullptr};
+    ~StepGraphs() { for (auto x : g) if (x) (void)hipGraphExecDestroy(x); }
+};
+
 // One step of every active view.  Two views run free of each other on their two streams: what was measured
 // (rocprofv3 kernel trace of both queues) is that two kernels that share the CUs each take about the sum of their solo
 // times - also an HBM-bound attention kernel beside a matrix-bound GEMM - so forcing the views half a block apart with
 // events (tried: -12 %) buys nothing; the gain of two views (+3.3 %) is the launch gaps and tails they fill for each other.
-int run_decode_step(asr_handle* h, DecView* views, const bool* active, int nviews, int t, int step)
+int run_decode_step(asr_handle* h, DecView* views, const bool* active, int nviews, int t, int step, StepGraphs* graphs)
 {
     for (int vi = 0; vi < nviews; ++vi) {
         if (!active[vi]) continue;
         const DecView& v = views[vi];
-        StepCtx c = step_ctx(h, v);
-        c.step = step;
-        if (h->profile && h->live_host && (size_t)(step + 1) * h->live_host_n <= h->live_host_cap)
-            HIP_TRY(h, hipMemcpyAsync(h->live_host + (size_t)step * h->live_host_n + v.n0, v.beam.live_cnt, (size_t)v.n * sizeof(int32_t),
-                                      hipMemcpyDeviceToHost, v.stream));
-        int rc = step == 1 ? step_head(h, v, c) : ASR_OK;           // later steps: beam_step_kernel wrote the decoder input
-        if (rc) return rc;
-        for (int l = 0; l < h->L; ++l) {
-            if ((rc = step_attention_half(h, v, c, l, t))) return rc;
-            if ((rc = step_ffn_half(h, v, c, l))) return rc;
+        if (graphs && step >= 2) {
+            if (!graphs->g[vi]) {
+                const int rc = capture_view_step(h, v, t, &graphs->g[vi]);
+                if (rc) return rc;
+            }
+            HIP_TRY(h, hipGraphLaunch(graphs->g[vi], v.stream));
+            continue;
         }
-        if ((rc = step_tail(h, v, c))) return rc;
+        const int rc = run_view_step(h, v, t, step);
+        if (rc) return rc;
     }
     return ASR_OK;
 }
@@ -851,13 +890,15 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     }
     for (int v = 0; v < nviews; ++v) HIP_TRY(h, launch_beam_init(views[v].beam, views[v].n, K, views[v].stream));
     constexpr int LOOKAHEAD = 3;
+    StepGraphs graphs;
+    const bool use_graph = h->use_graph && !h->profile && !tr;
     bool ended[MAX_VIEWS];
     for (int vi = 0; vi < MAX_VIEWS; ++vi) ended[vi] = vi >= nviews;
     auto all_ended = [&]() { for (int vi = 0; vi < nviews; ++vi) if (!ended[vi]) return false; return true; };
     for (int s = 1; s <= max_steps && !all_ended(); ++s) {
         bool active[MAX_VIEWS];
         for (int vi = 0; vi < MAX_VIEWS; ++vi) active[vi] = !ended[vi];
-        rc = run_decode_step(h, views, active, nviews, t, s);
+        rc = run_decode_step(h, views, active, nviews, t, s, use_graph ? &graphs : nullptr);
         if (rc) return rc;
         if (tr && s <= tr->steps) {
             const int buf = s & 1;
@@ -1081,6 +1122,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     if ((e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if (cfg->sub_batches) h->sub_batches = cfg->sub_batches;
     else if (const char* sb = getenv("ASR_AMD_SUBBATCH")) h->sub_batches = std::max(0, std::min(MAX_VIEWS, atoi(sb)));
+    if (const char* gr = getenv("ASR_AMD_GRAPH")) h->use_graph = atoi(gr) != 0;
     h->step_events.resize(8 * MAX_VIEWS);
     for (auto& ev : h->step_events)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");

@@ -141,6 +141,23 @@ def test_two_half_batches_on_two_streams_give_the_same_hypotheses(lens, beam, mt
         two.close()
 
 
+def test_graph_replay_of_the_decode_step_gives_the_same_hypotheses(monkeypatch):
+    """ASR_AMD_GRAPH=1: steps 2.. of each sub-batch are captured once per call into a HIP graph and replayed."""
+    ocfg = tiny_config(beam_size=4, max_target_length=40)
+    W = O.random_weights(ocfg, seed=41, bias_scale=0.1)
+    X = tiny_inputs((75, 40, 90, 33, 60), seed=42)
+    want, _, _ = _oracle_decode(X, W, ocfg, np.float32, 'kv')
+    monkeypatch.setenv('ASR_AMD_GRAPH', '1')
+    for parts in (1, 2, 3):
+        eng = _engine(ocfg, W, sub_batches=parts)
+        try:
+            assert np.array_equal(eng.decode(X), want), parts
+            assert np.array_equal(eng.decode(X[1:4]), want[1:4, :eng.decode(X[1:4]).shape[1]]), parts      # another shape: captured anew
+            assert np.array_equal(eng.decode(X), want), parts
+        finally:
+            eng.close()
+
+
 def test_profile_modes_bracket_every_launch_and_leave_the_hypotheses_alone():
     """asr_set_profile 1 (every bracket waited for) and 2 (brackets left in the two queues): the same classes and launch
     counts, times > 0, the same hypotheses as an unprofiled call; self-attention's bytes are the live rows streamed."""
