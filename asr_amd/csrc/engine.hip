@@ -1607,6 +1607,57 @@ int asr_op_add_layer_norm(asr_handle* h, const float* x, const float* delta, con
     return ASR_OK;
 }
 
+int asr_op_embedding(asr_handle* h, const float* emb, const int32_t* tokens, int32_t rows, int32_t vocab, int32_t hidden,
+                     int32_t position, int32_t scale, float* y)
+{
+    if (!h || !emb || !tokens || !y || rows < 1 || vocab < 1 || hidden != h->H || position < 0)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument (hidden must equal the handle's hidden_units, position >= 0)") : ASR_ERR_ARG;
+    for (int r = 0; r < rows; ++r)
+        if (tokens[r] < 0 || tokens[r] >= vocab) return fail(h, ASR_ERR_ARG, "token id outside [0, vocab)");
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = ensure_pe(h, position + 1))) return rc;
+    // the decode step's own kernel: it takes the token of row r from column `pos` of the prediction table of parity pos & 1
+    const int stride = position + 1;
+    std::vector<int32_t> preds((size_t)rows * stride, 3);
+    for (int r = 0; r < rows; ++r) preds[(size_t)r * stride + position] = tokens[r];
+    const int32_t scalars[2] = {position, 0};                        // pos, done
+    TmpBufs tb;
+    float *de, *dy;
+    int32_t *dp, *dsc;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, tb.up(&de, emb, (size_t)vocab * hidden, s));
+    HIP_TRY(h, tb.up(&dp, preds.data(), preds.size(), s));
+    HIP_TRY(h, tb.up(&dsc, scalars, (size_t)2, s));
+    HIP_TRY(h, tb.up<float>(&dy, nullptr, (size_t)rows * hidden, s));
+    const float mult = scale ? (float)sqrt((double)hidden) : 1.0f;
+    HIP_TRY(h, launch_embed_pe(de, dp, dp, stride, dsc, h->pe, mult, rows, hidden, dy, dsc + 1, s));
+    HIP_TRY(h, hipMemcpyAsync(y, dy, (size_t)rows * hidden * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
+int asr_op_pack_cross_kv(asr_handle* h, const float* kv, int32_t n, int32_t t, int32_t heads, int32_t as_bf16, void* k, void* v)
+{
+    if (!h || !kv || !k || !v || n < 1 || t < 1 || heads < 1 || heads > 64)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t hidden = (size_t)heads * ASR_D_HEAD, cnt = (size_t)n * t * hidden, esz = as_bf16 ? 2 : 4;
+    TmpBufs tb;
+    float* dkv;
+    char *dk, *dv;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, tb.up(&dkv, kv, cnt * 2, s));
+    HIP_TRY(h, tb.up<char>(&dk, nullptr, cnt * esz, s));
+    HIP_TRY(h, tb.up<char>(&dv, nullptr, cnt * esz, s));
+    HIP_TRY(h, launch_pack_cross_kv(dkv, n, t, heads, dk, dv, as_bf16 ? 1 : 0, s));
+    HIP_TRY(h, hipMemcpyAsync(k, dk, cnt * esz, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(v, dv, cnt * esz, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
 int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, const float* beta, int32_t n, int32_t t, int32_t hidden,
                              float* y)
 {

@@ -172,6 +172,17 @@ int asr_op_dense_glu(asr_handle* h, const float* x, const float* w1, const float
 int asr_op_add_layer_norm(asr_handle* h, const float* x, const float* delta, const float* dbias,
                           const float* scale, const float* bias, int32_t rows, int32_t hidden,
                           float* y);
+/* `embedding(...)` of the tokens fed at decode step `position` + that position's timing signal
+ * (model.py:569-576 with utils.embedding utils.py:509-526 and add_timing_signal_1d): y[r] = emb[tokens[r]] *
+ * (scale ? sqrt(hidden) : 1) + signal[position].  emb [vocab, hidden], hidden = the handle's hidden_units; runs the
+ * decode step's own kernel. */
+int asr_op_embedding(asr_handle* h, const float* emb, const int32_t* tokens, int32_t rows, int32_t vocab,
+                     int32_t hidden, int32_t position, int32_t scale, float* y);
+/* The layout step between the encoder-side K/V projection and the decode-time cross attention (no counterpart of its own
+ * in the reference: split_heads of utils.py:618-619 done once per utterance instead of once per step): kv [n*t, 2*heads*64]
+ * (k | v) -> k, v [n][heads][t][64], float32 or (as_bf16) bf16 rounded to nearest even (2-byte elements). */
+int asr_op_pack_cross_kv(asr_handle* h, const float* kv, int32_t n, int32_t t, int32_t heads, int32_t as_bf16,
+                         void* k, void* v);
 /* tf.contrib.layers.layer_norm over (t,hidden) per utterance + add_timing_signal_1d
  * (model.py:453,456): x [n,t,hidden] -> y. */
 int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, const float* beta,

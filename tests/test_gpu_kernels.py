@@ -273,3 +273,48 @@ def test_beam_step_bit_exact(L, eng, b, k):
     assert np.array_equal(tok, wt)
     assert np.array_equal(par, wp)
     assert np.array_equal(fo.astype(bool), wf)
+
+
+@pytest.mark.parametrize('rows,vocab,position,scale', [(7, 50, 0, 1), (40, 300, 13, 1), (3, 11, 200, 0), (1, 2, 511, 1)])
+def test_embedding_plus_timing_signal_bit_exact(L, eng, rows, vocab, position, scale):
+    """a14 (model.py:569-576): y = E[token] * sqrt(H) + signal[position]; one multiply and one add in float32, so the
+    decode step's kernel must give the numpy float32 evaluation of the oracle's expressions bit for bit."""
+    hidden = eng.hidden
+    rng = np.random.default_rng(rows * 31 + position)
+    E = rng.standard_normal((vocab, hidden)).astype(np.float32)
+    tok = rng.integers(0, vocab, rows).astype(np.int32)
+    tok[0] = vocab - 1
+    y = np.empty((rows, hidden), np.float32)
+    L.check(eng._h, L.lib.asr_op_embedding(eng._h, L.fptr(E), L.iptr(tok), rows, vocab, hidden, position, scale, L.fptr(y)))
+    cfg = tiny_config(hidden_units=hidden, scale_embedding=bool(scale))
+    want = O.embed(tok, {'decoder/dst_embedding/kernel': E}, cfg, np.float32) + O.timing_signal(position + 1, hidden)[position]
+    assert want.dtype == np.float32
+    assert np.array_equal(y, want)
+    # a token id outside the table is refused, not read
+    bad = tok.copy()
+    bad[-1] = vocab
+    assert L.lib.asr_op_embedding(eng._h, L.fptr(E), L.iptr(bad), rows, vocab, hidden, position, scale, L.fptr(y)) != 0
+
+
+@pytest.mark.parametrize('n,t,heads', [(1, 1, 2), (3, 77, 2), (2, 334, 16), (5, 64, 4)])
+def test_pack_cross_kv_is_the_head_major_copy(L, eng, n, t, heads):
+    """kv [n*t, 2H] (k | v) -> k, v [n][heads][t][64]: a pure copy in float32 (bit-exact against the numpy transpose,
+    = split_heads of utils.py:618-619), round-to-nearest-even bf16 for the bf16 caches of `precision: bf16`."""
+    H = heads * 64
+    rng = np.random.default_rng(n * 1000 + t)
+    kv = rng.standard_normal((n * t, 2 * H)).astype(np.float32)
+    kv[0, :4] = [1.00390625, -1.00390625, 1.01171875, 3.0e-41]        # bf16 ties (to even, both signs), a subnormal
+    want_k = kv[:, :H].reshape(n, t, heads, 64).transpose(0, 2, 1, 3)
+    want_v = kv[:, H:].reshape(n, t, heads, 64).transpose(0, 2, 1, 3)
+    k = np.empty((n, heads, t, 64), np.float32)
+    v = np.empty_like(k)
+    L.check(eng._h, L.lib.asr_op_pack_cross_kv(eng._h, L.fptr(kv), n, t, heads, 0, k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(k, want_k) and np.array_equal(v, want_v)
+    k16 = np.empty((n, heads, t, 64), np.uint16)
+    v16 = np.empty_like(k16)
+    L.check(eng._h, L.lib.asr_op_pack_cross_kv(eng._h, L.fptr(kv), n, t, heads, 1, k16.ctypes.data_as(C.c_void_p), v16.ctypes.data_as(C.c_void_p)))
+
+    def bf16_rne(x):
+        u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+        return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    assert np.array_equal(k16, bf16_rne(want_k)) and np.array_equal(v16, bf16_rne(want_v))
