@@ -104,7 +104,9 @@ struct asr_handle {
     // so that the launch gaps and tails of one half's kernels are filled by the other's (ASR_AMD_SUBBATCH=1 disables)
     hipStream_t xstream[3] = {nullptr, nullptr, nullptr};   // streams of sub-batches 1..3 (sub-batch 0 runs on `stream`)
     hipEvent_t fork_ev = nullptr;
-    bool use_graph = false;             // steps 2.. of the beam search replayed from a captured HIP graph (ASR_AMD_GRAPH)
+    int use_graph = -1;                 // steps 2.. of the beam search replayed from a captured HIP graph: 1 always, 0 never,
+                                        // -1 from 320 beam rows up (the sub-batch regime, where the host issues 100 000 launches a
+                                        // second without it); env ASR_AMD_GRAPH
     int sub_batches = 0;                // 0 = automatic (two halves from 320 rows), 1 = never, 2..4 = that many parts whenever n allows
 
     // profile
@@ -796,6 +798,7 @@ int capture_view_step(asr_handle* h, const DecView& v, int t, hipGraphExec_t* ou
 
 struct StepGraphs {                                                  // one per view, destroyed when the call returns
     hipGraphExec_t g[MAX_VIEWS] = {nullptr, nullptr, nullptr, nullptr};
+    bool disabled = false;                                           // a capture failed: direct launches for the rest of the call
     ~StepGraphs() { for (auto x : g) if (x) (void)hipGraphExecDestroy(x); }
 };
 
@@ -808,13 +811,16 @@ int run_decode_step(asr_handle* h, DecView* views, const bool* active, int nview
     for (int vi = 0; vi < nviews; ++vi) {
         if (!active[vi]) continue;
         const DecView& v = views[vi];
-        if (graphs && step >= 2) {
-            if (!graphs->g[vi]) {
-                const int rc = capture_view_step(h, v, t, &graphs->g[vi]);
-                if (rc) return rc;
+        if (graphs && !graphs->disabled && step >= 2) {
+            if (!graphs->g[vi] && capture_view_step(h, v, t, &graphs->g[vi]) != ASR_OK) {
+                graphs->g[vi] = nullptr;
+                graphs->disabled = true;                             // (a real launch error shows again below)
+                (void)hipGetLastError();
             }
-            HIP_TRY(h, hipGraphLaunch(graphs->g[vi], v.stream));
-            continue;
+            if (graphs->g[vi]) {
+                HIP_TRY(h, hipGraphLaunch(graphs->g[vi], v.stream));
+                continue;
+            }
         }
         const int rc = run_view_step(h, v, t, step);
         if (rc) return rc;
@@ -891,7 +897,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     for (int v = 0; v < nviews; ++v) HIP_TRY(h, launch_beam_init(views[v].beam, views[v].n, K, views[v].stream));
     constexpr int LOOKAHEAD = 3;
     StepGraphs graphs;
-    const bool use_graph = h->use_graph && !h->profile && !tr;
+    const bool use_graph = (h->use_graph < 0 ? R >= 320 : h->use_graph != 0) && !h->profile && !tr;
     bool ended[MAX_VIEWS];
     for (int vi = 0; vi < MAX_VIEWS; ++vi) ended[vi] = vi >= nviews;
     auto all_ended = [&]() { for (int vi = 0; vi < nviews; ++vi) if (!ended[vi]) return false; return true; };
@@ -1122,7 +1128,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     if ((e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if (cfg->sub_batches) h->sub_batches = cfg->sub_batches;
     else if (const char* sb = getenv("ASR_AMD_SUBBATCH")) h->sub_batches = std::max(0, std::min(MAX_VIEWS, atoi(sb)));
-    if (const char* gr = getenv("ASR_AMD_GRAPH")) h->use_graph = atoi(gr) != 0;
+    if (const char* gr = getenv("ASR_AMD_GRAPH")) h->use_graph = atoi(gr) != 0 ? 1 : 0;
     h->step_events.resize(8 * MAX_VIEWS);
     for (auto& ev : h->step_events)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");

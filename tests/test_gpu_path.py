@@ -142,13 +142,14 @@ def test_two_half_batches_on_two_streams_give_the_same_hypotheses(lens, beam, mt
 
 
 def test_graph_replay_of_the_decode_step_gives_the_same_hypotheses(monkeypatch):
-    """ASR_AMD_GRAPH=1: steps 2.. of each sub-batch are captured once per call into a HIP graph and replayed."""
+    """ASR_AMD_GRAPH=1 (the default from 320 beam rows up): steps 2.. of each sub-batch are captured once per call into a
+    HIP graph and replayed; =0: every kernel launched by the host."""
     ocfg = tiny_config(beam_size=4, max_target_length=40)
     W = O.random_weights(ocfg, seed=41, bias_scale=0.1)
     X = tiny_inputs((75, 40, 90, 33, 60), seed=42)
     want, _, _ = _oracle_decode(X, W, ocfg, np.float32, 'kv')
-    monkeypatch.setenv('ASR_AMD_GRAPH', '1')
-    for parts in (1, 2, 3):
+    for parts, graph in ((1, '1'), (2, '1'), (3, '1'), (2, '0')):
+        monkeypatch.setenv('ASR_AMD_GRAPH', graph)
         eng = _engine(ocfg, W, sub_batches=parts)
         try:
             assert np.array_equal(eng.decode(X), want), parts
