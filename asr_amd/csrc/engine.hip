@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <deque>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -257,11 +258,13 @@ inline bool pack_planes(const asr_handle* h, const float* w, int n, int k, uint1
 const char* gemm_class_name(int nprod, int M, int N, int K, int epilogue, int split_k)
 {
     static std::map<std::string, std::string> interned;           // stable c_str() for ProfClass::name
+    static std::mutex interned_mu;                                // handles on other GPUs / other host threads share it
     const int tile = nprod == 0 ? gemm_f32_pick_tile(M, N, split_k, epilogue) : gemm_split_pick_tile(M, N, K, split_k, epilogue);
     std::string n = nprod == 0 ? "gemm_f32_nt" : nprod == 13 ? "gemm_f16x3_nt" : nprod == 6 ? "gemm_bf16x6_nt" : nprod == 3 ? "gemm_bf16x3_nt" : "gemm_bf16_nt";
     if (nprod) n += tile == 1 ? "<128,128," : tile == 5 ? "<160,128," : tile == 6 ? "<96,256," : tile == 7 || tile == 9 ? "<64,256," : "<64,128,";
     else n += tile == 1 ? "<128,128," : tile == 4 ? "<128,64," : "<64,64,";
     n += epilogue == EPI_GLU ? "GLU>" : epilogue == EPI_PARTIAL ? "PARTIAL>" : epilogue == EPI_BIAS ? "BIAS>" : "ACT>";
+    std::lock_guard<std::mutex> lock(interned_mu);
     auto it = interned.find(n);
     if (it == interned.end()) it = interned.emplace(n, n).first;
     return it->second.c_str();
@@ -283,7 +286,7 @@ int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float
     if (nprod == 6 && dual_format(h, K)) a.Wp += gemm_split_weight_elems(N, K, 2);        // the bf16x6 copy (a repeated call)
     a.range_flag = nprod == 13 ? h->range_flag : nullptr;
     const double wbytes = nprod ? 2.0 * gemm_split_planes(nprod) : 4.0;
-    ProfScope ps(h, gemm_class_name(nprod, M, N, K, epilogue, split_k), 2.0 * M * N * (double)K,
+    ProfScope ps(h, h->profile ? gemm_class_name(nprod, M, N, K, epilogue, split_k) : "", 2.0 * M * N * (double)K,
                  4.0 * ((double)M * K + (double)M * nout) + wbytes * (double)N * K, stream);
     if (nprod) HIP_TRY(h, launch_gemm_split(a, nprod, 0, stream));
     else HIP_TRY(h, launch_gemm_f32(a, 0, stream));

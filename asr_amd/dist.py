@@ -95,20 +95,59 @@ def gather_hypotheses(local_ids, local_hyps, n_total, width, group=None, device=
 def decode_sharded(decode_fn, feats, tokens_per_batch, beam, max_target_length, rank=0, world_size=1,
                    group=None, device=None):
     """Bucket `feats` (list of [T_u, D] arrays) by length, deal the batches over ranks, decode this
-    rank's batches with `decode_fn(X) -> Y`, gather.  Returns int32 [len(feats), max_target_length+1]."""
+    rank's batches with `decode_fn(X) -> Y`, gather.  Returns int32 [len(feats), max_target_length+1].
+
+    `decode_fn` may be a list of callables (one per engine handle on this rank's GPU, each with its own
+    weight replica, K/V cache and streams): the rank's batches are then decoded by that many host threads
+    side by side, most expensive first.  Bucketed batches are small (ten-odd utterances) and a small batch is
+    bound by kernel latency, not by the GPU, so two or three of them share the GPU almost for free; the
+    hypotheses do not depend on it (utterances are independent, every batch is decoded exactly as alone)."""
+    fns = list(decode_fn) if isinstance(decode_fn, (list, tuple)) else [decode_fn]
     lengths = [len(f) for f in feats]
     batches = bucket_batches(lengths, tokens_per_batch)
     costs = [batch_cost(len(b), max(lengths[i] for i in b), beam, max_target_length) for b in batches]
     mine = assign_batches(costs, world_size)[rank]
-    ids, hyps = [], []
-    for bi in mine:
+
+    def make(bi):
         idx = batches[bi]
         tmax = max(lengths[i] for i in idx)
         X = np.zeros((len(idx), tmax, feats[idx[0]].shape[1]), np.float32)
         for r, i in enumerate(idx):
             X[r, :lengths[i]] = feats[i]
-        Y = decode_fn(X)
-        for r, i in enumerate(idx):
+        return X
+
+    results = {}
+    if len(fns) == 1 or len(mine) < 2:
+        for bi in mine:
+            results[bi] = fns[0](make(bi))
+    else:
+        import queue
+        import threading
+        todo = queue.Queue()
+        for bi in sorted(mine, key=lambda b: -costs[b]):
+            todo.put(bi)
+        errors = []
+
+        def worker(fn):
+            while not errors:
+                try:
+                    bi = todo.get_nowait()
+                except queue.Empty:
+                    return
+                try:
+                    results[bi] = fn(make(bi))
+                except Exception as ex:          # re-raised on the calling thread
+                    errors.append(ex)
+        threads = [threading.Thread(target=worker, args=(fn,)) for fn in fns]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if errors:
+            raise errors[0]
+    ids, hyps = [], []
+    for bi in mine:
+        for r, i in enumerate(batches[bi]):
             ids.append(i)
-            hyps.append(Y[r])
+            hyps.append(results[bi][r])
     return gather_hypotheses(ids, hyps, len(feats), max_target_length + 1, group=group, device=device)

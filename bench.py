@@ -209,8 +209,10 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
 
     cfg = bench_config(args.beam, args.max_target_length, args.precision, args.vocab)
     W = weights.random_init(cfg, seed=0)
-    eng = Engine(cfg, local_rank)
-    eng.load_weights(W)
+    engines = [Engine(cfg, local_rank) for _ in range(max(1, args.engines_per_gpu))]
+    for e in engines:
+        e.load_weights(W)
+    eng = engines[0]
     n_total = world * args.utts_per_gpu
     rng = np.random.default_rng(4242)                                  # every rank builds the same utterance list
     raw_lens = [int(x) for x in rng.integers(200, 1501, size=n_total)]
@@ -222,17 +224,23 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
     owners = D.assign_batches(costs, world)
     model_load = [sum(costs[i] for i in o) for o in owners]
     busy = [0.0]
+    import threading
+    busy_lock = threading.Lock()
 
-    def decode_fn(X):
-        t0 = time.perf_counter()
-        Y = eng.decode(X)
-        busy[0] += time.perf_counter() - t0
-        return Y
+    def make_decode_fn(e):
+        def decode_fn(X):
+            t0 = time.perf_counter()
+            Y = e.decode(X)
+            with busy_lock:
+                busy[0] += time.perf_counter() - t0
+            return Y
+        return decode_fn
+    decode_fns = [make_decode_fn(e) for e in engines]
 
     device = None if (rehearse or world == 1) else torch.device('cuda', local_rank)
 
     def step():
-        return D.decode_sharded(decode_fn, feats, args.tokens_per_batch, args.beam, args.max_target_length, rank=rank,
+        return D.decode_sharded(decode_fns, feats, args.tokens_per_batch, args.beam, args.max_target_length, rank=rank,
                                 world_size=world, device=device)
 
     def fence():
@@ -268,21 +276,23 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
             'dtype': PRECISION_INFO[args.precision][0], 'data': 'synthetic',
             'config': {'workload': 'bucketed: %d utterances per GPU, T_raw ~ U[200,1500] (%.0f audio-s in all), 10-frame length '
                                    'buckets closed above %d stacked frames (utils.py:285-323), %d batches dealt over %d rank(s) by '
-                                   'cost, host features (H2D inside the step), one all_gather of the hypotheses; char '
+                                   'cost and decoded by %d engine handle(s) per GPU side by side, host features (H2D inside the step), one all_gather of the hypotheses; char '
                                    'architecture with V=%d, beam %d, max_target_length %d, random-init weights'
-                                   % (args.utts_per_gpu, sum(raw_lens) / 100.0, args.tokens_per_batch, len(batches), world, args.vocab,
+                                   % (args.utts_per_gpu, sum(raw_lens) / 100.0, args.tokens_per_batch, len(batches), world, len(engines), args.vocab,
                                       args.beam, args.max_target_length),
-                       'parallelism': 'dp%d' % world, 'precision': args.precision, 'batches': len(batches),
+                       'parallelism': 'dp%d' % world, 'precision': args.precision, 'batches': len(batches), 'engines_per_gpu': len(engines),
                        'batch_sizes': sorted(len(b) for b in batches)[::max(1, len(batches) // 16)],
                        'range_retries': eng.range_retries()},
-            # per-rank seconds inside Engine.decode over the timed steps, and how even the deal was
+            # per-rank seconds inside Engine.decode over the timed steps (summed over the rank's engine threads), and how even the deal was
             'per_rank_busy_s': [round(b, 4) for b in busy_all],
             'load_balance': {'measured_max_over_mean': max(busy_all) / (sum(busy_all) / len(busy_all)),
                              'cost_model_max_over_mean': max(model_load) / (sum(model_load) / len(model_load))},
             'hypotheses_shape': list(Y.shape),
+            'hypotheses_crc32': int(__import__('zlib').crc32(np.ascontiguousarray(Y).tobytes())),   # same for any number of engines / ranks
         }
         print(json.dumps(out), flush=True)
-    eng.close()
+    for e in engines:
+        e.close()
 
 
 def main():
@@ -302,7 +312,9 @@ def main():
     ap.add_argument('--alt-steps', type=int, default=3)
     ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_f16x3'), choices=sorted(PRECISION_INFO))
     ap.add_argument('--workload', default='fixed', choices=['fixed', 'bucketed'])
-    ap.add_argument('--utts-per-gpu', type=int, default=64, help='--workload bucketed: utterances per GPU')
+    ap.add_argument('--utts-per-gpu', type=int, default=512, help='--workload bucketed: utterances per GPU (a test set of a few hundred utterances fills the 10-frame buckets; 64 leaves mostly single-utterance batches)')
+    ap.add_argument('--engines-per-gpu', type=int, default=2, help='--workload bucketed: engine handles (weight replica, K/V cache, '
+                    'streams, one host thread each) that decode the rank\'s batches side by side')
     ap.add_argument('--tokens-per-batch', type=int, default=7000, help='--workload bucketed: stacked frames per batch '
                     '(test.tokens_per_batch of the SEAME yaml)')
     args = ap.parse_args()

@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,3 +75,26 @@ def test_world_size_2_gloo_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] == res[1] == single.tolist()
+
+
+def test_decode_sharded_with_several_decode_fns_gives_the_same_rows_and_propagates_errors():
+    """decode_fn may be a list (one callable per engine handle of the rank's GPU): the batches are decoded by that many
+    host threads; same result as one callable; an exception in a worker is re-raised on the caller."""
+    import threading
+    from asr_amd import dist as D
+    rng = np.random.default_rng(5)
+    feats = [rng.standard_normal((int(n), 4)).astype(np.float32) for n in rng.integers(50, 140, 40)]
+    one = D.decode_sharded(_fake_decode, feats, 300, 2, 6)
+    used = set()
+
+    def tagged(X):
+        used.add(threading.get_ident())
+        return _fake_decode(X)
+    many = D.decode_sharded([tagged, tagged, tagged], feats, 300, 2, 6)
+    assert np.array_equal(one, many)
+    assert len(used) >= 2
+
+    def boom(X):
+        raise RuntimeError('decode failed')
+    with pytest.raises(RuntimeError, match='decode failed'):
+        D.decode_sharded([boom, boom], feats, 300, 2, 6)

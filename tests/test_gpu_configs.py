@@ -282,5 +282,14 @@ def test_decode_sharded_real_engine_matches_oracle_on_the_same_bucketed_batches(
         assert np.array_equal(got, want)
         if world == 1:                                            # and the one-call form
             assert np.array_equal(D.decode_sharded(eng.decode, feats, tokens_per_batch, ocfg.beam_size, ocfg.max_target_length), want)
+            # ... with the rank's batches decoded by several engine handles of the one GPU side by side (host threads)
+            more = [_engine(ocfg, W), _engine(ocfg, W)]
+            try:
+                fns = [e.decode for e in [eng] + more]
+                for _ in range(2):
+                    assert np.array_equal(D.decode_sharded(fns, feats, tokens_per_batch, ocfg.beam_size, ocfg.max_target_length), want)
+            finally:
+                for e in more:
+                    e.close()
     finally:
         eng.close()
