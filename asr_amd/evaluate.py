@@ -8,6 +8,7 @@ same `uttid<TAB>hypothesis` output with BPE markers stripped.  Unlike the refere
 from __future__ import annotations
 
 import codecs
+import collections
 import logging
 import os
 import re
@@ -73,14 +74,22 @@ class Evaluator(object):
         tmp = output_path + '.tmp'
         count, token_count = 0, 0
         start = time.time()
-        with codecs.open(tmp, 'w', 'utf8') as fd:
+        meta = collections.deque()
+
+        def features():
             for X, uttids in self.data_reader.get_test_batches(src_path, batch_size):
-                Y = self.beam_search(X)
+                meta.append((len(X), uttids))
+                yield X
+        with codecs.open(tmp, 'w', 'utf8') as fd:
+            # == `Y = self.beam_search(X)` per batch, in order; with the build's `test.engines_per_gpu` >= 2 the next
+            # batch is already being decoded while this one is written out
+            for Y in self.model.predict_batches(features()):
+                n_x, uttids = meta.popleft()
                 sents = self.data_reader.indices_to_words(Y)
-                assert len(X) == len(sents)
+                assert n_x == len(sents)
                 for sent, uttid in zip(sents, uttids):
                     fd.write(uttid + '\t' + sent + '\n')
-                count += len(X)
+                count += n_x
                 token_count += int(np.sum(np.not_equal(Y, 3)))   # 3: </s>
                 time_span = time.time() - start
                 logging.info('{0} sentences ({1} tokens) processed in {2:.2f} minutes (speed: {3:.4f} sec/token).'.

@@ -254,6 +254,73 @@ def default_device():
     return 0
 
 
+class EnginePool(object):
+    """Several engine handles on ONE GPU - each with its own weight replica, K/V cache, workspaces and streams - driven by
+    one host thread each, so that whole batches are decoded side by side (no counterpart in the reference, whose
+    `translate` loop runs one `sess.run` at a time, evaluate.py:52-66).  A batch of the reference's size leaves an MI355X
+    short of work in two ways: ten-utterance bucketed batches are bound by kernel latency, and a 64-utterance batch has
+    launch gaps and tails that a second batch's kernels fill.  Measured: 64 x 10 s utterances, beam 10: 291 ms a batch with
+    one handle (two half batches on two streams), 239 ms with two handles each running whole-batch kernels; three and
+    four are slower again.  Every batch is decoded exactly as if alone: same hypotheses.
+
+    Unless the YAML sets `test.sub_batches`, the handles of a pool of two or more run each batch as ONE run of
+    whole-batch kernels (the batches themselves are what overlaps)."""
+
+    def __init__(self, config, device=0, engines=2):
+        import copy
+        n = max(1, int(engines))
+        cfg = config
+        if n > 1 and config.test.sub_batches is None and not os.environ.get('ASR_AMD_SUBBATCH'):
+            cfg = copy.deepcopy(config)
+            cfg.test['sub_batches'] = 1
+        self.engines = [Engine(cfg, device) for _ in range(n)]
+
+    def load_weights(self, variables):
+        for e in self.engines:
+            e.load_weights(variables)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def map(self, call, items):
+        """Ordered iterator over call(engine, item) for item in items, with as many items in flight as there are
+        handles (items are drawn lazily, at most that many ahead of the results consumed)."""
+        if len(self.engines) == 1:
+            for it in items:
+                yield call(self.engines[0], it)
+            return
+        import collections
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+        free = queue.Queue()
+        for e in self.engines:
+            free.put(e)
+
+        def run(it):
+            e = free.get()
+            try:
+                return call(e, it)
+            finally:
+                free.put(e)
+        pending = collections.deque()
+        with ThreadPoolExecutor(max_workers=len(self.engines)) as ex:
+            try:
+                for it in items:
+                    pending.append(ex.submit(run, it))
+                    if len(pending) >= len(self.engines):
+                        yield pending.popleft().result()
+                while pending:
+                    yield pending.popleft().result()
+            finally:
+                for f in pending:
+                    f.cancel()
+
+    def decode_many(self, batches):
+        """Y of every X in `batches`, in order."""
+        return self.map(lambda e, X: e.decode(X), batches)
+
+
 class Model(object):
     """Inference-only counterpart of model.Model (model.py:18-45,162-204).
 
@@ -272,6 +339,9 @@ class Model(object):
             else:
                 devices = list(range(max(1, min(self._num_towers, visible_devices()))))
         self._devices = list(devices)
+        # build extension (not a reference key): engine handles per GPU, see EnginePool
+        self._engines_per_gpu = max(1, int((config.test.engines_per_gpu if config.test else None) or os.environ.get('ASR_AMD_ENGINES') or 1))
+        self.pools = []
         self.engines = []
         self.encoder_scope = 'encoder'
         self.decoder_scope = 'decoder'
@@ -279,11 +349,24 @@ class Model(object):
     def build_test_model(self, reuse=None):
         logging.info('Build test model.')
         if not self.engines:
-            self.engines = [Engine(self._config, d) for d in self._devices]
+            self.pools = [EnginePool(self._config, d, self._engines_per_gpu) for d in self._devices]
+            self.engines = [p.engines[0] for p in self.pools]          # predict / loss: the first handle of every GPU
 
     def restore(self, variables):
-        for e in self.engines:
-            e.load_weights(variables)
+        for p in self.pools:
+            p.load_weights(variables)
+
+    def close(self):
+        for p in self.pools:
+            p.close()
+        self.pools, self.engines = [], []
+
+    def predict_batches(self, batches):
+        """predict(X) for every X of `batches`, in order.  One tower on one GPU with `test.engines_per_gpu` >= 2: that many
+        batches are in flight at a time (EnginePool); otherwise one after the other, like evaluate.py:52-66."""
+        if self._num_towers == 1 and len(self.pools) == 1 and len(self.pools[0].engines) > 1:
+            return self.pools[0].map(lambda e, X: e.decode(np.asarray(X, dtype=np.float32)), batches)
+        return (self.predict(X) for X in batches)
 
     def predict(self, X):
         """== sess.run(self.prediction, expand_feed_dict({self.src_pls: X}))."""

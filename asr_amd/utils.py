@@ -29,6 +29,8 @@ class AttrDict(dict):
     plain dict is wrapped on first access (utils.py:27-40)."""
 
     def __getattr__(self, item):
+        if item.startswith('__') and item.endswith('__'):      # copy / pickle protocol probes are not configuration keys
+            raise AttributeError(item)
         if item not in self:
             return None
         if type(self[item]) is dict:

@@ -8,9 +8,13 @@ max_target_length 200, 64 synthetic 10-second utterances per GPU per step.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU; every rank decodes its own 64-utterance batch (weak scaling, utterances are
-independent), then the hypotheses are gathered with one RCCL all_gather of a fixed-width int32
+One process per GPU; every rank decodes its own 64-utterance batch per step (weak scaling, utterances are
+independent), then the step's hypotheses are gathered with one RCCL all_gather of a fixed-width int32
 buffer (the path's only exchange, model.py:192-201).  Rank 0 prints ONE JSON line.
+A step = one 64-utterance batch through the whole path.  By default TWO steps are in flight on every GPU
+(`--in-flight 2`: two engine handles, asr_amd.model.EnginePool, each decoding whole steps one after the other): the
+K timed steps are the same K batches decoded the same way, `ms_per_step` = elapsed / K; the line also carries
+`one_step_at_a_time` (the same measurement with `--in-flight 1`).
 
 The same line also carries, at N = 1 (all timed by this run, on this box):
   roofline            dominant kernel class, HIP events around every launch of one extra pass that launches the same
@@ -298,7 +302,7 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--t-raw', type=int, default=1000)
@@ -309,7 +313,10 @@ def main():
     ap.add_argument('--cpu-sample-utts', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-precisions', action='store_true')
-    ap.add_argument('--alt-steps', type=int, default=3)
+    ap.add_argument('--no-one-at-a-time', action='store_true', help='skip the one_step_at_a_time leg (profiling runs)')
+    ap.add_argument('--alt-steps', type=int, default=4)
+    ap.add_argument('--in-flight', type=int, default=2, help='steps (whole batches) being decoded at any time on one GPU, each by an '
+                    'engine handle of its own (asr_amd.model.EnginePool); 1 = one step at a time')
     ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_f16x3'), choices=sorted(PRECISION_INFO))
     ap.add_argument('--workload', default='fixed', choices=['fixed', 'bucketed'])
     ap.add_argument('--utts-per-gpu', type=int, default=512, help='--workload bucketed: utterances per GPU (a test set of a few hundred utterances fills the 10-frame buckets; 64 leaves mostly single-utterance batches)')
@@ -348,10 +355,14 @@ def main():
             dist.destroy_process_group()
         return
 
+    from asr_amd.model import EnginePool
     cfg = bench_config(args.beam, args.max_target_length, args.precision, args.vocab)
     W = weights.random_init(cfg, seed=0)
-    eng = Engine(cfg, local_rank)
-    eng.load_weights(W)
+    # `--in-flight` engine handles on the GPU (asr_amd.model.EnginePool: own weight replica, K/V cache and streams, one host
+    # thread each): that many steps (whole 64-utterance batches) are being decoded at any time, each exactly as if alone
+    pool = EnginePool(cfg, local_rank, args.in_flight)
+    pool.load_weights(W)
+    eng = pool.engines[0]
 
     n, t_raw = args.batch, args.t_raw
     raw = synthetic_raw(n, t_raw, seed=1000 + rank)
@@ -360,15 +371,24 @@ def main():
     width = args.max_target_length + 1
     front = (t_raw, 80, 3, 0, 3)
 
-    def step(e=eng):
-        Y = e.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
-        if world > 1:      # gather the hypotheses (fixed width, padded with 3) on every rank
+    def decode(e, _=None):
+        return e.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
+
+    def gather(Y):          # the hypotheses of a step (fixed width, padded with 3) on every rank: the path's only exchange
+        if world > 1:
             buf = torch.full((n, width), 3, dtype=torch.int32)
             buf[:, :Y.shape[1]] = torch.from_numpy(Y)
             if not rehearse:
                 buf = buf.cuda(local_rank)
             out = [torch.empty_like(buf) for _ in range(world)]
             dist.all_gather(out, buf)
+
+    def run_steps(p, k):
+        """k steps through pool p: results come back in step order on this thread, which gathers each while the
+        pool's threads go on decoding the next ones."""
+        Y = None
+        for Y in p.map(decode, range(k)):
+            gather(Y)
         return Y
 
     def fence():
@@ -377,15 +397,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    Y = None
-    for _ in range(args.warmup):
-        Y = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        Y = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(p, k):
+        fence()
+        t0 = time.perf_counter()
+        Y = run_steps(p, k)
+        fence()
+        return time.perf_counter() - t0, Y
+
+    # W untimed steps - and at least one on every handle, so that no handle's first call falls into the timed region
+    Y = run_steps(pool, max(args.warmup, len(pool.engines)) if args.warmup > 0 else 0)
+    elapsed, Y = timed(pool, args.steps)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -393,6 +414,7 @@ def main():
 
     if rank == 0:
         audio_s = world * n * t_raw / 100.0 * args.steps
+        nfl = len(pool.engines)
         out = {
             'metric': 'decoded audio-sec/sec (RTFx) whole node, char unit512 block6, beam=%d' % args.beam,
             'value': audio_s / elapsed, 'unit': 'audio-sec/sec', 'n_gpus': world, 'steps': args.steps,
@@ -400,24 +422,35 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': PRECISION_INFO[args.precision][0], 'data': 'synthetic',
             'config': {'workload': '%s (hidden 1024, 16 heads, 6+6 blocks, GLU 4096, tied V=%d), beam %d, '
                                    'max_target_length %d, %d x %.0f s synthetic fbank utterances per GPU per step '
-                                   '(T=%d stacked frames), random-init weights, %d decode steps taken'
+                                   '(T=%d stacked frames), random-init weights, %d decode steps taken; %s'
                                    % ('char config' if args.vocab == 3900 else 'char architecture with another vocabulary',
                                       args.vocab, args.beam, args.max_target_length, n, t_raw / 100.0, (t_raw + 2) // 3,
-                                      Y.shape[1]),
+                                      Y.shape[1],
+                                      ('%d steps in flight per GPU: %d engine handles, each decoding whole steps one after the '
+                                       'other as one run of %d-row kernels; ms_per_step = elapsed / steps' % (nfl, nfl, n * args.beam))
+                                      if nfl > 1 else 'one step at a time'),
                        'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world, 'precision': args.precision,
+                       'steps_in_flight': nfl,
                        # precision f32_f16x3: calls the library repeated on the bf16x6 kernels because an operand left
                        # fp16's range (0 = every timed step ran on the fp16x3 kernels)
-                       'range_retries': eng.range_retries()},
+                       'range_retries': sum(e.range_retries() for e in pool.engines)},
         }
-        # ---- roofline of the dominant kernel: HIP events around every launch of one extra pass, on the stream each
-        # kernel is launched on, left in the queues and read back afterwards (profile mode 2): the same sub-batches side
-        # by side as in the timed passes, i.e. the durations rocprofv3 --kernel-trace reports for this command.  A second
-        # pass waits for every bracket (mode 1): each kernel alone on the GPU, reported as `solo_us` ----
+        # ---- roofline of the dominant kernel: HIP events around every launch of one extra step on the first handle, on the
+        # stream each kernel is launched on, left in the queues and read back afterwards (profile mode 2), while the
+        # other handle(s) decode a step of their own beside it: the conditions of the timed region, i.e. the durations
+        # rocprofv3 --kernel-trace reports for this command.  A second step with every bracket waited for and nothing
+        # beside it (mode 1) gives each kernel alone on the GPU: `solo_us` ----
+        import threading
         eng.set_profile(2)
-        eng.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
+        others = [threading.Thread(target=lambda e=e: [decode(e) for _ in range(2)]) for e in pool.engines[1:]]
+        for th in others:
+            th.start()
+        decode(eng)
         prof = eng.get_profile()
+        for th in others:
+            th.join()
         eng.set_profile(1)
-        eng.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
+        decode(eng)
         solo = {p['name']: p for p in eng.get_profile()}
         eng.set_profile(0)
         out['roofline'], out['kernels'] = roofline_of(prof, args.precision)
@@ -425,44 +458,60 @@ def main():
             p1 = solo.get(k['name'])
             if p1 and p1['launches']:
                 k['solo_us'] = round(1000.0 * p1['ms'] / p1['launches'], 2)
+        # `achieved` / `frac` are per launch AS TIMED, i.e. with the other handle's kernels sharing the GPU (a kernel then
+        # has about half the chip); the same class alone on the GPU:
+        rf = out['roofline']
+        rf['steps_in_flight'] = nfl
+        p1 = solo.get(rf['kernel'])
+        if p1 and p1['ms'] > 0:
+            rf['solo_avg_us'] = 1000.0 * p1['ms'] / p1['launches']
+            rf['solo_frac'] = rf['frac'] * rf['avg_us'] / rf['solo_avg_us']
         if world == 1 and not args.no_cpu_baseline:
             cb, Yc = cpu_baseline(cfg, W, raw, min(args.cpu_sample_utts, n))
             m = min(Yc.shape[1], Y.shape[1])
             cb['hypotheses_match_gpu'] = bool(np.array_equal(Yc[:, :m], Y[:Yc.shape[0], :m]))
             out['cpu_baseline'] = cb
             out['cpu_baseline_ref_shaped'] = cpu_baseline_ref_shaped(cfg, W, raw)
+        pool.close()
+        pool = None
+        if world == 1 and nfl > 1 and not args.no_one_at_a_time:
+            # the same steps one at a time (one handle, the library's default: two half batches on two streams)
+            p1 = EnginePool(cfg, local_rank, 1)
+            p1.load_weights(W)
+            run_steps(p1, 1)
+            dt, Y1 = timed(p1, args.alt_steps)
+            m = min(Y1.shape[1], Y.shape[1])
+            same = np.all(Y1[:, :m] == Y[:, :m], axis=1)
+            out['one_step_at_a_time'] = {'value': n * t_raw / 100.0 * args.alt_steps / dt, 'unit': 'audio-sec/sec',
+                                         'ms_per_step': 1000.0 * dt / max(args.alt_steps, 1), 'steps': args.alt_steps,
+                                         'utterances_identical': '%d of %d' % (int(same.sum()), n)}
+            p1.close()
         if world == 1 and not args.no_alt_precisions:
-            # the other dense-layer arithmetics on the same batch, timed by this same run (fresh handle each; the
-            # headline handle is closed first so that only one set of weights and caches is resident)
-            eng.close()
-            eng = None
+            # the other dense-layer arithmetics on the same batch, timed by this same run the same way (fresh handles;
+            # the headline's are closed first)
             alts = {}
             for prec in ('f32_bf16x6', 'f32', 'bf16'):
                 if prec == args.precision:
                     continue
-                e2 = Engine(bench_config(args.beam, args.max_target_length, prec, args.vocab), local_rank)
-                e2.load_weights(W)
-                Ya = step(e2)                                            # warm-up
-                torch.cuda.synchronize()
-                ta = time.perf_counter()
-                for _ in range(args.alt_steps):
-                    Ya = step(e2)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - ta) / max(args.alt_steps, 1)
+                p2 = EnginePool(bench_config(args.beam, args.max_target_length, prec, args.vocab), local_rank, args.in_flight)
+                p2.load_weights(W)
+                run_steps(p2, len(p2.engines))                           # warm-up
+                dt, Ya = timed(p2, args.alt_steps)
                 m = min(Ya.shape[1], Y.shape[1])
                 same = np.all(Ya[:, :m] == Y[:, :m], axis=1)
-                alts[prec] = {'value': n * t_raw / 100.0 / dt, 'unit': 'audio-sec/sec', 'ms_per_step': 1000.0 * dt,
+                alts[prec] = {'value': n * t_raw / 100.0 * args.alt_steps / dt, 'unit': 'audio-sec/sec',
+                              'ms_per_step': 1000.0 * dt / max(args.alt_steps, 1),
                               'steps': args.alt_steps, 'dtype': PRECISION_INFO[prec][0].split(' (')[0],
                               # against the default mode's hypotheses on this batch: random-init weights over 201 steps
                               # leave near-ties, so one f32-rounding-level difference can turn an utterance's beam
                               'hypotheses_match': bool(Ya.shape == Y.shape and same.all()),
                               'utterances_identical': '%d of %d' % (int(same.sum()), n)}
-                e2.close()
+                p2.close()
             out['alt_precisions'] = alts
         print(json.dumps(out), flush=True)
 
-    if eng is not None:
-        eng.close()
+    if pool is not None:
+        pool.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -152,8 +152,10 @@ def _write_vocab_bpe(path, n):
     return words
 
 
-def test_evaluator_end_to_end_from_checkpoint_dir_to_hypothesis_file(tmp_path):
-    """evaluate.py:25-38,52-74: Evaluator().init_from_config(config) restores tf.train.latest_checkpoint(model_dir) (a
+@pytest.mark.parametrize('engines_per_gpu', [None, 2])
+def test_evaluator_end_to_end_from_checkpoint_dir_to_hypothesis_file(tmp_path, engines_per_gpu):
+    """(`engines_per_gpu` = the build's `test.engines_per_gpu` key: batches decoded two at a time by two engine handles -
+    the same file.)  evaluate.py:25-38,52-74: Evaluator().init_from_config(config) restores tf.train.latest_checkpoint(model_dir) (a
     TF-V2 bundle with optimizer slots and global_step beside the graph variables), translate() batches the scp in
     order, decodes, writes `uttid<TAB>tokens` and strips the BPE markers.  Expected file = the oracle's hypotheses
     through the reference's indices_to_words + sed expression, byte for byte."""
@@ -195,6 +197,8 @@ def test_evaluator_end_to_end_from_checkpoint_dir_to_hypothesis_file(tmp_path):
         'test': {'batch_size': 2, 'max_target_length': 14, 'lp_alpha': 0.6, 'beam_size': 3, 'num_gpus': 1,
                  'set1': {'src_path': scp, 'ref_path': 'unused', 'output_path': out_path, 'cmd': None}},
     }
+    if engines_per_gpu:
+        cfg_yaml['test']['engines_per_gpu'] = engines_per_gpu
     cfg_path = str(tmp_path / 'config.yaml')
     with open(cfg_path, 'w') as f:
         yaml.safe_dump(cfg_yaml, f)
@@ -202,12 +206,12 @@ def test_evaluator_end_to_end_from_checkpoint_dir_to_hypothesis_file(tmp_path):
     ev = Evaluator()
     ev.init_from_config(config)
     try:
+        assert len(ev.model.pools[0].engines) == (engines_per_gpu or 1)
         for attr in config.test:                                                # evaluate.py:126-128
             if attr.startswith('set'):
                 assert ev.evaluate(config.test.batch_size, **config.test[attr]) is None
     finally:
-        for e in ev.model.engines:
-            e.close()
+        ev.model.close()
     # expected: scp-order batches of 2 (utils.py:384-403), each decoded on its own (Q1 / Q7 depend on the batch's padding)
     lines = []
     idx2 = {i: t for i, t in enumerate(words)}

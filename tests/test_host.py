@@ -191,3 +191,53 @@ def test_product_path_never_imports_the_oracle():
                 assert 'oracle' not in re.sub(r'#.*', '', src).replace('asr_oracle', 'oracle') or \
                     not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+
+
+def test_engine_pool_map_keeps_order_bounds_what_is_in_flight_and_propagates_errors():
+    """asr_amd.model.EnginePool.map with stand-in handles (no GPU): results in item order, at most one item per handle
+    in flight, items drawn lazily, a failing call re-raised at its place in the order."""
+    import threading
+    import time
+    from asr_amd.model import EnginePool
+
+    class Fake(object):
+        def __init__(self, tag):
+            self.tag = tag
+    pool = object.__new__(EnginePool)
+    pool.engines = [Fake(0), Fake(1), Fake(2)]
+    lock = threading.Lock()
+    state = {'now': 0, 'peak': 0, 'drawn': 0}
+    busy = set()
+
+    def call(e, item):
+        with lock:
+            assert e.tag not in busy                         # a handle serves one call at a time
+            busy.add(e.tag)
+            state['now'] += 1
+            state['peak'] = max(state['peak'], state['now'])
+        time.sleep(0.002 * (5 - item % 5))                   # later items may finish first
+        with lock:
+            busy.discard(e.tag)
+            state['now'] -= 1
+        if item == 17:
+            raise ValueError('item 17')
+        return item * item
+
+    def items(n):
+        for i in range(n):
+            state['drawn'] = i + 1
+            yield i
+    got = []
+    for r in pool.map(call, items(12)):
+        got.append(r)
+        assert state['drawn'] <= len(got) + len(pool.engines)     # lazily: never further ahead than the handles can hold
+    assert got == [i * i for i in range(12)]
+    assert 2 <= state['peak'] <= 3
+    out = []
+    with pytest.raises(ValueError, match='item 17'):
+        for r in pool.map(call, items(30)):
+            out.append(r)
+    assert out == [i * i for i in range(17)]
+    # one handle: plain sequential calls on the caller's thread
+    pool.engines = [Fake(0)]
+    assert list(pool.map(lambda e, it: (threading.get_ident(), it), range(3))) == [(threading.get_ident(), i) for i in range(3)]
