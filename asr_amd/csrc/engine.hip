@@ -142,6 +142,16 @@ int fail(asr_handle* h, int code, const std::string& msg)
     return code;
 }
 
+// Blocking copy on the handle's own stream.  (The plain hipMemcpy runs on the legacy stream, which the runtime ties to
+// every other stream of the process: it is refused while ANOTHER handle's thread is capturing its decode step into a graph,
+// and it is a meeting point of handles that should run free of each other.)
+hipError_t copy_blocking(asr_handle* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t stream = nullptr)
+{
+    if (!stream) stream = h->stream;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(stream);
+}
+
 int dev_alloc(asr_handle* h, void** p, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
@@ -320,7 +330,7 @@ int ensure_pe(asr_handle* h, int rows)
     std::vector<float> t = timing_table(rows, h->H);
     int rc = dev_alloc_t(h, &h->pe, t.size());
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpy(h->pe, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, copy_blocking(h, h->pe, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     h->pe_rows = rows;
     return ASR_OK;
 }
@@ -388,7 +398,7 @@ int upload(asr_handle* h, const std::string& name, float** dst)
     const HostTensor& t = h->staged.at(name);
     int rc = dev_alloc_t(h, dst, t.data.size());
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpy(*dst, t.data.data(), t.data.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, copy_blocking(h, *dst, t.data.data(), t.data.size() * sizeof(float), hipMemcpyHostToDevice));
     return ASR_OK;
 }
 
@@ -399,7 +409,7 @@ int upload_gemm_host(asr_handle* h, const float* w, int n, int k, float** dst)
     if (gemm_nprod(h, k) == 0) {
         int rc = dev_alloc_t(h, dst, count);
         if (rc) return rc;
-        HIP_TRY(h, hipMemcpy(*dst, w, count * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(h, copy_blocking(h, *dst, w, count * sizeof(float), hipMemcpyHostToDevice));
         return ASR_OK;
     }
     std::vector<uint16_t> planes(plane_elems(h, n, k));
@@ -407,7 +417,7 @@ int upload_gemm_host(asr_handle* h, const float* w, int n, int k, float** dst)
     uint16_t* d = nullptr;
     int rc = dev_alloc_t(h, &d, planes.size());
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpy(d, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(h, copy_blocking(h, d, planes.data(), planes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     *dst = reinterpret_cast<float*>(d);
     return ASR_OK;
 }
@@ -444,7 +454,7 @@ int upload_ffn1(asr_handle* h, const std::string& p, float** w, float** b)
     if (rc) return rc;
     rc = dev_alloc_t(h, b, bp.size());
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpy(*b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, copy_blocking(h, *b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
     return ASR_OK;
 }
 
@@ -785,7 +795,11 @@ int run_view_step(asr_handle* h, const DecView& v, int t, int step)
 // per step and view instead of 70, and the queue holds the whole step when its first kernel starts.
 int capture_view_step(asr_handle* h, const DecView& v, int t, hipGraphExec_t* out)
 {
-    HIP_TRY(h, hipStreamBeginCapture(v.stream, hipStreamCaptureModeThreadLocal));
+    // One capture at a time in the process, and in the mode that leaves other threads' calls alone: other handles (other
+    // host threads) go on allocating, copying and synchronising on their own streams while this one records its step.
+    static std::mutex capture_mu;
+    std::lock_guard<std::mutex> lock(capture_mu);
+    HIP_TRY(h, hipStreamBeginCapture(v.stream, hipStreamCaptureModeRelaxed));
     const int rc = run_view_step(h, v, t, 2);
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(v.stream, &g);
@@ -890,6 +904,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     DecView views[MAX_VIEWS];
     for (int vi = 0, n0 = 0; vi < nviews; ++vi) {   // the first n % nviews parts get one utterance more
         const int nv = n / nviews + (vi < n % nviews ? 1 : 0);
+        if (vi > 0 && !h->xstream[vi - 1]) HIP_TRY(h, hipStreamCreateWithFlags(&h->xstream[vi - 1], hipStreamNonBlocking));
         views[vi] = make_view(h, vi, n0, nv, t, vi == 0 ? h->stream : h->xstream[vi - 1]);
         n0 += nv;
     }
@@ -913,21 +928,21 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
             const int buf = s & 1;
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             int32_t posd[2];
-            HIP_TRY(h, hipMemcpy(posd, h->beam.pos, sizeof(posd), hipMemcpyDeviceToHost));
+            HIP_TRY(h, copy_blocking(h, posd, h->beam.pos, sizeof(posd), hipMemcpyDeviceToHost));
             if (posd[0] == s) {                                                                     // the step really ran
                 if (tr->logits) {
                     float* dst = tr->logits + (size_t)(s - 1) * R * h->V;
                     const size_t cnt = (size_t)R * h->V;
-                    HIP_TRY(h, hipMemcpy(dst, h->logits, cnt * 4, hipMemcpyDeviceToHost));
+                    HIP_TRY(h, copy_blocking(h, dst, h->logits, cnt * 4, hipMemcpyDeviceToHost));
                     if (h->logit_split > 1) {                   // second K slice, added in slab order like the top-k kernel does
                         std::vector<float> slab(cnt);
-                        HIP_TRY(h, hipMemcpy(slab.data(), h->logits + cnt, cnt * 4, hipMemcpyDeviceToHost));
+                        HIP_TRY(h, copy_blocking(h, slab.data(), h->logits + cnt, cnt * 4, hipMemcpyDeviceToHost));
                         for (size_t i = 0; i < cnt; ++i) dst[i] += slab[i];
                     }
                 }
-                if (tr->scores) HIP_TRY(h, hipMemcpy(tr->scores + (size_t)(s - 1) * R, h->beam.scores[buf], (size_t)R * 4, hipMemcpyDeviceToHost));
-                if (tr->tokens) HIP_TRY(h, hipMemcpy(tr->tokens + (size_t)(s - 1) * R, h->beam.tokens, (size_t)R * 4, hipMemcpyDeviceToHost));
-                if (tr->parents) HIP_TRY(h, hipMemcpy(tr->parents + (size_t)(s - 1) * R, h->beam.parents, (size_t)R * 4, hipMemcpyDeviceToHost));
+                if (tr->scores) HIP_TRY(h, copy_blocking(h, tr->scores + (size_t)(s - 1) * R, h->beam.scores[buf], (size_t)R * 4, hipMemcpyDeviceToHost));
+                if (tr->tokens) HIP_TRY(h, copy_blocking(h, tr->tokens + (size_t)(s - 1) * R, h->beam.tokens, (size_t)R * 4, hipMemcpyDeviceToHost));
+                if (tr->parents) HIP_TRY(h, copy_blocking(h, tr->parents + (size_t)(s - 1) * R, h->beam.parents, (size_t)R * 4, hipMemcpyDeviceToHost));
             }
         }
         for (int vi = 0; vi < nviews; ++vi) {
@@ -947,7 +962,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     for (int vi = 0; vi < nviews; ++vi) {
         HIP_TRY(h, hipStreamSynchronize(views[vi].stream));
         int32_t posd[2] = {0, 0};
-        HIP_TRY(h, hipMemcpy(posd, views[vi].beam.pos, sizeof(posd), hipMemcpyDeviceToHost));
+        HIP_TRY(h, copy_blocking(h, posd, views[vi].beam.pos, sizeof(posd), hipMemcpyDeviceToHost, views[vi].stream));
         lens[vi] = posd[0];
         if (!posd[1] || lens[vi] < 1 || lens[vi] > max_steps)
             return fail(h, ASR_ERR_HIP, "beam search loop ended in an inconsistent state");
@@ -972,8 +987,8 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
         const int buf = lens[vi] & 1, rv = v.n * K;
         std::vector<int32_t> preds((size_t)rv * width);
         std::vector<float> scores(rv);
-        HIP_TRY(h, hipMemcpy(preds.data(), v.beam.preds[buf], preds.size() * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(h, hipMemcpy(scores.data(), v.beam.scores[buf], scores.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, copy_blocking(h, preds.data(), v.beam.preds[buf], preds.size() * 4, hipMemcpyDeviceToHost, v.stream));
+        HIP_TRY(h, copy_blocking(h, scores.data(), v.beam.scores[buf], scores.size() * 4, hipMemcpyDeviceToHost, v.stream));
         finalize_host(preds.data(), scores.data(), v.n, K, width, lens[vi], h->cfg.lp_alpha, Y + (size_t)v.n0 * len, len);
     }
     *len_out = len;
@@ -1045,9 +1060,10 @@ int with_range_retry(asr_handle* h, F&& run)
     int rc = run();
     if (rc != ASR_OK || h->nprod != 13 || h->nprod_active != 13) return rc;
     int32_t flag = 0;
-    HIP_TRY(h, hipMemcpy(&flag, h->range_flag, sizeof(flag), hipMemcpyDeviceToHost));
+    HIP_TRY(h, copy_blocking(h, &flag, h->range_flag, sizeof(flag), hipMemcpyDeviceToHost));
     if (!flag && !h->weights_out_of_range) return ASR_OK;
-    HIP_TRY(h, hipMemset(h->range_flag, 0, sizeof(flag)));
+    HIP_TRY(h, hipMemsetAsync(h->range_flag, 0, sizeof(flag), h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->range_retries += 1;
     h->nprod_active = 6;
     rc = run();
@@ -1123,11 +1139,15 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     }
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->range_flag), 16)) != hipSuccess) return hip_fail(e, "hipMalloc");
-    if ((e = hipMemset(h->range_flag, 0, 16)) != hipSuccess) return hip_fail(e, "hipMemset");
+    // first work on the stream here, at creation: the runtime binds a stream to one of the process's hardware queues when it
+    // is first used, and handles that are first used at the same moment from several host threads were seen to end up on
+    // one queue (their kernels then never overlap)
+    if ((e = hipMemsetAsync(h->range_flag, 0, 16, h->stream)) != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
     if ((e = hipEventCreate(&h->pe0)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->pe1)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-    for (auto& xs : h->xstream)
-        if ((e = hipStreamCreateWithFlags(&xs, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+    // (the streams of sub-batches 1..3 are created when a call first runs that many parts: a process has few hardware
+    //  queues - 4 by default - and streams share them in creation order, so a handle that runs whole batches should hold one)
     if ((e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     if (cfg->sub_batches) h->sub_batches = cfg->sub_batches;
     else if (const char* sb = getenv("ASR_AMD_SUBBATCH")) h->sub_batches = std::max(0, std::min(MAX_VIEWS, atoi(sb)));

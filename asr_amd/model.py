@@ -285,36 +285,71 @@ class EnginePool(object):
 
     def map(self, call, items):
         """Ordered iterator over call(engine, item) for item in items, with as many items in flight as there are
-        handles (items are drawn lazily, at most that many ahead of the results consumed)."""
+        handles (items are drawn lazily, at most that many ahead of the results consumed).  Every handle is driven by
+        a host thread of its own for the whole of the iteration."""
         if len(self.engines) == 1:
             for it in items:
                 yield call(self.engines[0], it)
             return
-        import collections
-        import queue
-        from concurrent.futures import ThreadPoolExecutor
-        free = queue.Queue()
-        for e in self.engines:
-            free.put(e)
+        n = len(self.engines)
+        source = iter(items)
+        cond = threading.Condition()
+        st = {'next_in': 0, 'next_out': 0, 'exhausted': False, 'stop': False, 'results': {}}
 
-        def run(it):
-            e = free.get()
-            try:
-                return call(e, it)
-            finally:
-                free.put(e)
-        pending = collections.deque()
-        with ThreadPoolExecutor(max_workers=len(self.engines)) as ex:
-            try:
-                for it in items:
-                    pending.append(ex.submit(run, it))
-                    if len(pending) >= len(self.engines):
-                        yield pending.popleft().result()
-                while pending:
-                    yield pending.popleft().result()
-            finally:
-                for f in pending:
-                    f.cancel()
+        class _Failed(object):
+            def __init__(self, ex):
+                self.ex = ex
+
+        def worker(e):
+            while True:
+                with cond:
+                    while not st['stop'] and not st['exhausted'] and st['next_in'] - st['next_out'] >= n:
+                        cond.wait()
+                    if st['stop'] or st['exhausted']:
+                        return
+                    try:
+                        item = next(source)
+                    except StopIteration:
+                        st['exhausted'] = True
+                        cond.notify_all()
+                        return
+                    except Exception as ex:          # the caller's generator failed: surfaces at this place in the order
+                        st['results'][st['next_in']] = _Failed(ex)
+                        st['next_in'] += 1
+                        st['exhausted'] = True
+                        cond.notify_all()
+                        return
+                    idx = st['next_in']
+                    st['next_in'] += 1
+                try:
+                    r = call(e, item)
+                except Exception as ex:
+                    r = _Failed(ex)
+                with cond:
+                    st['results'][idx] = r
+                    cond.notify_all()
+        threads = [threading.Thread(target=worker, args=(e,), daemon=True) for e in self.engines]
+        for th in threads:
+            th.start()
+        try:
+            while True:
+                with cond:
+                    while st['next_out'] not in st['results'] and not (st['exhausted'] and st['next_out'] >= st['next_in']):
+                        cond.wait()
+                    if st['next_out'] not in st['results']:
+                        return
+                    r = st['results'].pop(st['next_out'])
+                    st['next_out'] += 1
+                    cond.notify_all()
+                if isinstance(r, _Failed):
+                    raise r.ex
+                yield r
+        finally:
+            with cond:
+                st['stop'] = True
+                cond.notify_all()
+            for th in threads:
+                th.join()
 
     def decode_many(self, batches):
         """Y of every X in `batches`, in order."""

@@ -11,8 +11,8 @@ max_target_length 200, 64 synthetic 10-second utterances per GPU per step.
 One process per GPU; every rank decodes its own 64-utterance batch per step (weak scaling, utterances are
 independent), then the step's hypotheses are gathered with one RCCL all_gather of a fixed-width int32
 buffer (the path's only exchange, model.py:192-201).  Rank 0 prints ONE JSON line.
-A step = one 64-utterance batch through the whole path.  By default TWO steps are in flight on every GPU
-(`--in-flight 2`: two engine handles, asr_amd.model.EnginePool, each decoding whole steps one after the other): the
+A step = one 64-utterance batch through the whole path.  By default FOUR steps are in flight on every GPU
+(`--in-flight 4`: four engine handles, asr_amd.model.EnginePool, each decoding whole steps one after the other): the
 K timed steps are the same K batches decoded the same way, `ms_per_step` = elapsed / K; the line also carries
 `one_step_at_a_time` (the same measurement with `--in-flight 1`).
 
@@ -43,6 +43,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# Streams of one process share its hardware queues (4 by default) in creation order, and kernels of two streams that share
+# a queue do not overlap.  The benchmark keeps several engine handles busy on one GPU, each on a stream of its own, so it
+# asks the HIP runtime for 8 queues - before anything initialises it.  (Measured, 64-utterance steps: 3 handles on 4
+# queues 225 ms a step, 4 handles on 8 queues 214 ms; 4 handles on 4 queues 243 ms.)
+HW_QUEUES = 8
+try:
+    if int(os.environ.get('GPU_MAX_HW_QUEUES', '0') or 0) < HW_QUEUES:
+        os.environ['GPU_MAX_HW_QUEUES'] = str(HW_QUEUES)
+except ValueError:
+    os.environ['GPU_MAX_HW_QUEUES'] = str(HW_QUEUES)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: BF16 dense MFMA peak
@@ -302,7 +313,7 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--t-raw', type=int, default=1000)
@@ -314,13 +325,13 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-precisions', action='store_true')
     ap.add_argument('--no-one-at-a-time', action='store_true', help='skip the one_step_at_a_time leg (profiling runs)')
-    ap.add_argument('--alt-steps', type=int, default=4)
-    ap.add_argument('--in-flight', type=int, default=2, help='steps (whole batches) being decoded at any time on one GPU, each by an '
+    ap.add_argument('--alt-steps', type=int, default=8)
+    ap.add_argument('--in-flight', type=int, default=4, help='steps (whole batches) being decoded at any time on one GPU, each by an '
                     'engine handle of its own (asr_amd.model.EnginePool); 1 = one step at a time')
     ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_f16x3'), choices=sorted(PRECISION_INFO))
     ap.add_argument('--workload', default='fixed', choices=['fixed', 'bucketed'])
     ap.add_argument('--utts-per-gpu', type=int, default=512, help='--workload bucketed: utterances per GPU (a test set of a few hundred utterances fills the 10-frame buckets; 64 leaves mostly single-utterance batches)')
-    ap.add_argument('--engines-per-gpu', type=int, default=2, help='--workload bucketed: engine handles (weight replica, K/V cache, '
+    ap.add_argument('--engines-per-gpu', type=int, default=4, help='--workload bucketed: engine handles (weight replica, K/V cache, '
                     'streams, one host thread each) that decode the rank\'s batches side by side')
     ap.add_argument('--tokens-per-batch', type=int, default=7000, help='--workload bucketed: stacked frames per batch '
                     '(test.tokens_per_batch of the SEAME yaml)')
@@ -430,7 +441,7 @@ def main():
                                        'other as one run of %d-row kernels; ms_per_step = elapsed / steps' % (nfl, nfl, n * args.beam))
                                       if nfl > 1 else 'one step at a time'),
                        'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world, 'precision': args.precision,
-                       'steps_in_flight': nfl,
+                       'steps_in_flight': nfl, 'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')),
                        # precision f32_f16x3: calls the library repeated on the bf16x6 kernels because an operand left
                        # fp16's range (0 = every timed step ran on the fp16x3 kernels)
                        'range_retries': sum(e.range_retries() for e in pool.engines)},

@@ -81,6 +81,7 @@ def test_decode_sharded_with_several_decode_fns_gives_the_same_rows_and_propagat
     """decode_fn may be a list (one callable per engine handle of the rank's GPU): the batches are decoded by that many
     host threads; same result as one callable; an exception in a worker is re-raised on the caller."""
     import threading
+    import time
     from asr_amd import dist as D
     rng = np.random.default_rng(5)
     feats = [rng.standard_normal((int(n), 4)).astype(np.float32) for n in rng.integers(50, 140, 40)]
@@ -89,6 +90,7 @@ def test_decode_sharded_with_several_decode_fns_gives_the_same_rows_and_propagat
 
     def tagged(X):
         used.add(threading.get_ident())
+        time.sleep(0.01)                                     # long enough for the other threads to get their turn
         return _fake_decode(X)
     many = D.decode_sharded([tagged, tagged, tagged], feats, 300, 2, 6)
     assert np.array_equal(one, many)

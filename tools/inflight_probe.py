@@ -40,9 +40,14 @@ def main():
         per = 4
         outs = [None] * n_eng
 
+        errors = []
+
         def work(j):
-            for _ in range(per):
-                outs[j] = engines[j].decode_dev(d_raw.data_ptr(), 64, 0, 0, raw=front)
+            try:
+                for _ in range(per):
+                    outs[j] = engines[j].decode_dev(d_raw.data_ptr(), 64, 0, 0, raw=front)
+            except Exception as ex:
+                errors.append(ex)
         for e in engines:                                     # warm-up
             e.decode_dev(d_raw.data_ptr(), 64, 0, 0, raw=front)
         torch.cuda.synchronize()
@@ -54,6 +59,9 @@ def main():
             x.join()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if errors:
+            print('%d engine(s) x %d sub-batch(es): FAILED: %s' % (n_eng, sb, errors[0]), flush=True)
+            sys.exit(1)
         nb = n_eng * per
         if ref is None:
             ref = outs[0]
