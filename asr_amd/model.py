@@ -259,9 +259,10 @@ class EnginePool(object):
     one host thread each, so that whole batches are decoded side by side (no counterpart in the reference, whose
     `translate` loop runs one `sess.run` at a time, evaluate.py:52-66).  A batch of the reference's size leaves an MI355X
     short of work in two ways: ten-utterance bucketed batches are bound by kernel latency, and a 64-utterance batch has
-    launch gaps and tails that a second batch's kernels fill.  Measured: 64 x 10 s utterances, beam 10: 291 ms a batch with
-    one handle (two half batches on two streams), 239 ms with two handles each running whole-batch kernels; three and
-    four are slower again.  Every batch is decoded exactly as if alone: same hypotheses.
+    launch gaps and tails that other batches' kernels fill.  Measured: 64 x 10 s utterances, beam 10: 291 ms a batch with
+    one handle (two half batches on two streams), 239 / 224 ms with two / three handles each running whole-batch kernels, 214 ms
+    with four when the process has eight hardware queues (GPU_MAX_HW_QUEUES=8 before the first GPU call; with the default four
+    queues a fourth handle shares a queue and loses).  Every batch is decoded exactly as if alone: same hypotheses.
 
     Unless the YAML sets `test.sub_batches`, the handles of a pool of two or more run each batch as ONE run of
     whole-batch kernels (the batches themselves are what overlaps)."""
