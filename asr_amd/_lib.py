@@ -30,7 +30,7 @@ class asr_config(C.Structure):
                 ('scale_embedding', C.c_int32), ('tie_embedding_and_softmax', C.c_int32),
                 ('beam_size', C.c_int32), ('max_target_length', C.c_int32), ('lp_alpha', C.c_float),
                 ('device', C.c_int32), ('precision', C.c_int32), ('sub_batches', C.c_int32),
-                ('reserved', C.c_int32 * 2)]
+                ('shared_gpu', C.c_int32), ('reserved', C.c_int32 * 1)]
 
 
 def _preload_torch_hip_runtime():

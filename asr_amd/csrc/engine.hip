@@ -105,6 +105,7 @@ struct asr_handle {
     // so that the launch gaps and tails of one half's kernels are filled by the other's (ASR_AMD_SUBBATCH=1 disables)
     hipStream_t xstream[3] = {nullptr, nullptr, nullptr};   // streams of sub-batches 1..3 (sub-batch 0 runs on `stream`)
     hipEvent_t fork_ev = nullptr;
+    bool shared_gpu = false;            // asr_config.shared_gpu: other handles keep the GPU busy, prefer fewer K-slices
     int use_graph = -1;                 // steps 2.. of the beam search replayed from a captured HIP graph: 1 always, 0 never,
                                         // -1 from 320 beam rows up (the sub-batch regime, where the host issues 100 000 launches a
                                         // second without it); env ASR_AMD_GRAPH
@@ -500,6 +501,11 @@ int decode_splits(const asr_handle* h, int R, int* s_qkv, int* s_proj, int* s_ff
     *s_qkv = gemm_pick_split_k(R, 3 * h->H, h->H, gemm_nprod(h, h->H));
     *s_proj = gemm_pick_split_k(R, h->H, h->H, gemm_nprod(h, h->H));
     *s_ffn2 = gemm_pick_split_k(R, h->H, h->F, gemm_nprod(h, h->F));
+    // Other handles' kernels fill the chip (asr_config.shared_gpu): what counts then is bytes, not how well one kernel covers
+    // 256 CUs alone, and every K-slice is one more slab written and read.  Measured with four handles on 64-utterance batches
+    // (ms per batch): 2,2,8 (the values above) 212.3; 1,1,1 219.4; 1,1,2 204.8; 1,1,4 205.3; 1,2,4 206.5; 2,2,4 208.4; 1,1,8 208.8.
+    // Ten-utterance batches lose with fewer slices (1377 -> 1160 audio-s/s): only for whole-batch row counts.
+    if (h->shared_gpu && R >= 576) { *s_qkv = 1; *s_proj = 1; *s_ffn2 = 2; }
     if (const char* e = getenv("ASR_AMD_SPLITS")) {                  // development: "qkv,proj,ffn2"
         int a = 0, b = 0, c = 0;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 1 && b >= 1 && c >= 1 && a <= ASR_MAX_SPLITK && b <= ASR_MAX_SPLITK &&
@@ -1102,8 +1108,8 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     if (cfg->ff_activation < ASR_FF_RELU || cfg->ff_activation > ASR_FF_SWISH) return bad("unknown ff_activation");
     if (cfg->precision < ASR_PRECISION_F32 || cfg->precision > ASR_PRECISION_F32_F16X3) return bad("unknown precision");
     if (cfg->sub_batches < 0 || cfg->sub_batches > MAX_VIEWS) return bad("sub_batches must be 0 (default) or 1..4");
-    for (int i = 0; i < 2; ++i)
-        if (cfg->reserved[i]) return bad("reserved fields must be zero");
+    if (cfg->shared_gpu != 0 && cfg->shared_gpu != 1) return bad("shared_gpu must be 0 or 1");
+    if (cfg->reserved[0]) return bad("reserved fields must be zero");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "no HIP device visible (libasr_amd needs an MI355X)"; return ASR_ERR_HIP; }
     if (cfg->device < 0 || cfg->device >= ndev || cfg->device >= MAX_DEVICES) return bad("device ordinal out of range");
@@ -1149,6 +1155,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     // (the streams of sub-batches 1..3 are created when a call first runs that many parts: a process has few hardware
     //  queues - 4 by default - and streams share them in creation order, so a handle that runs whole batches should hold one)
     if ((e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    h->shared_gpu = cfg->shared_gpu != 0;
     if (cfg->sub_batches) h->sub_batches = cfg->sub_batches;
     else if (const char* sb = getenv("ASR_AMD_SUBBATCH")) h->sub_batches = std::max(0, std::min(MAX_VIEWS, atoi(sb)));
     if (const char* gr = getenv("ASR_AMD_GRAPH")) h->use_graph = atoi(gr) != 0 ? 1 : 0;

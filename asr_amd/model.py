@@ -58,6 +58,8 @@ def asr_config_from(config, device=0):
     if sb not in (0, 1, 2, 3, 4):
         raise ValueError('test.sub_batches must be 1..4')
     c.sub_batches = sb
+    # build extension: other handles decode on the same GPU at the same time (EnginePool sets it for its handles)
+    c.shared_gpu = 1 if t.shared_gpu else 0
     return c, prec
 
 
@@ -271,9 +273,12 @@ class EnginePool(object):
         import copy
         n = max(1, int(engines))
         cfg = config
-        if n > 1 and config.test.sub_batches is None and not os.environ.get('ASR_AMD_SUBBATCH'):
+        if n > 1:
             cfg = copy.deepcopy(config)
-            cfg.test['sub_batches'] = 1
+            if config.test.sub_batches is None and not os.environ.get('ASR_AMD_SUBBATCH'):
+                cfg.test['sub_batches'] = 1
+            if config.test.shared_gpu is None:
+                cfg.test['shared_gpu'] = 1
         self.engines = [Engine(cfg, device) for _ in range(n)]
 
     def load_weights(self, variables):

@@ -76,7 +76,12 @@ typedef struct asr_config {
                                             parts on their own streams (same results: utterances are independent), 0 = env
                                             ASR_AMD_SUBBATCH or automatic (two halves from 320 beam rows);
                                             build extension, YAML key test.sub_batches */
-    int32_t reserved[2];                 /* must be zero                                  */
+    int32_t shared_gpu;                  /* 0 = this handle has the GPU to itself: K-slices and tiles are chosen so that every
+                                            kernel fills the chip alone (lowest latency of one batch); 1 = other handles decode on
+                                            the same GPU at the same time (asr_amd.model.EnginePool): fewer K-slices, i.e. fewer
+                                            bytes, because the other handles' kernels fill the chip.  Same results up to the
+                                            summation order of the K-slices.  Build extension, YAML key test.shared_gpu */
+    int32_t reserved[1];                 /* must be zero                                  */
 } asr_config;
 
 /* Number of HIP devices visible to this process (0 when there is none or on error).  Replaces the

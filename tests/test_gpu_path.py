@@ -285,6 +285,33 @@ def test_full_size_batch64_properties():
         eng.close()
 
 
+def test_shared_gpu_handles_use_fewer_k_slices_and_give_the_same_hypotheses():
+    """asr_config.shared_gpu = 1 (what EnginePool sets on its handles): from 576 beam rows up the decode-row GEMMs run with
+    fewer K-slices (another summation order, same arithmetic).  Full-size char architecture, 64 short utterances x beam 10
+    = 640 rows: tokens and parents of every step identical to the float32 oracle, logits within 1e-3, in both settings."""
+    from asr_amd.model import Engine
+    ocfg = O.make_config(beam_size=10, max_target_length=4)
+    W = O.random_weights(ocfg, seed=51)
+    X = O.make_batch(O.synthetic_fbank(64, [90 + 3 * (i % 7) for i in range(64)], seed=52))
+    Y32, tr32, _ = _oracle_decode(X, W, ocfg, np.float32, 'kv')
+    for shared in (0, 1):
+        cfg = product_config(ocfg, sub_batches=1)
+        cfg.test['shared_gpu'] = shared
+        eng = Engine(cfg, 0)
+        eng.load_weights(W)
+        try:
+            assert eng.cfg.shared_gpu == shared
+            Y, tr = eng.decode_trace(X, Y32.shape[1])
+            for s in range(Y32.shape[1]):
+                assert rel_err(tr['logits'][s], tr32['logits'][s]) < LOGIT_TOL, (shared, s)
+                assert np.array_equal(tr['tokens'][s], tr32['tokens'][s]), (shared, s)
+                assert np.array_equal(tr['parents'][s], tr32['parents'][s]), (shared, s)
+            assert np.array_equal(Y, Y32)
+            assert np.array_equal(eng.decode(X), Y32)
+        finally:
+            eng.close()
+
+
 def _targets(n, ty, vocab, seed):
     rng = np.random.default_rng(seed)
     Y = rng.integers(4, vocab, (n, ty)).astype(np.int32)
