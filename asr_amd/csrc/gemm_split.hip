@@ -74,7 +74,7 @@ __device__ __forceinline__ f32x16 mma32(const u32x4& a, const u32x4& b, const f3
 }
 
 template <int MI, int NI, int NW, int EPI, int NPROD>
-__global__ __launch_bounds__(NW * 64) void gemm_split_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4 ? 3 : 2))) void gemm_split_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
 {
     static_assert(NW == 4 || NW == 8, "4 or 8 waves side by side");
     constexpr int FPT = 2048 / (NW * 64);              // floats of a 64 x 32 A pass per thread: 8 (4 waves) or 4 (8 waves)
