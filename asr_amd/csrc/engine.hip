@@ -266,11 +266,20 @@ inline bool pack_planes(const asr_handle* h, const float* w, int n, int k, uint1
     return ok;
 }
 
-const char* gemm_class_name(int nprod, int M, int N, int K, int epilogue, int split_k)
+// Tile of the split GEMM for this handle: handles that share the GPU (asr_config.shared_gpu) do not take the 96 x 256 tile -
+// it exists to get a whole-batch launch through the chip in ONE round of workgroups, at the price of 5 % padded rows, and
+// with other handles' kernels in the queue there are no idle rounds to avoid (four steps in flight, same box: 203.0 -> 201.7 ms).
+inline int split_tile_for(const asr_handle* h, int M, int N, int K, int split_k, int epilogue)
+{
+    const int t = gemm_split_pick_tile(M, N, K, split_k, epilogue);
+    return (t == 6 && h->shared_gpu) ? 9 : t;
+}
+
+const char* gemm_class_name(const asr_handle* h, int nprod, int M, int N, int K, int epilogue, int split_k)
 {
     static std::map<std::string, std::string> interned;           // stable c_str() for ProfClass::name
     static std::mutex interned_mu;                                // handles on other GPUs / other host threads share it
-    const int tile = nprod == 0 ? gemm_f32_pick_tile(M, N, split_k, epilogue) : gemm_split_pick_tile(M, N, K, split_k, epilogue);
+    const int tile = nprod == 0 ? gemm_f32_pick_tile(M, N, split_k, epilogue) : split_tile_for(h, M, N, K, split_k, epilogue);
     std::string n = nprod == 0 ? "gemm_f32_nt" : nprod == 13 ? "gemm_f16x3_nt" : nprod == 6 ? "gemm_bf16x6_nt" : nprod == 3 ? "gemm_bf16x3_nt" : "gemm_bf16_nt";
     if (nprod) n += tile == 1 ? "<128,128," : tile == 5 ? "<160,128," : tile == 6 ? "<96,256," : tile == 7 || tile == 9 ? "<64,256," : "<64,128,";
     else n += tile == 1 ? "<128,128," : tile == 4 ? "<128,64," : "<64,64,";
@@ -297,9 +306,9 @@ int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float
     if (nprod == 6 && dual_format(h, K)) a.Wp += gemm_split_weight_elems(N, K, 2);        // the bf16x6 copy (a repeated call)
     a.range_flag = nprod == 13 ? h->range_flag : nullptr;
     const double wbytes = nprod ? 2.0 * gemm_split_planes(nprod) : 4.0;
-    ProfScope ps(h, h->profile ? gemm_class_name(nprod, M, N, K, epilogue, split_k) : "", 2.0 * M * N * (double)K,
+    ProfScope ps(h, h->profile ? gemm_class_name(h, nprod, M, N, K, epilogue, split_k) : "", 2.0 * M * N * (double)K,
                  4.0 * ((double)M * K + (double)M * nout) + wbytes * (double)N * K, stream);
-    if (nprod) HIP_TRY(h, launch_gemm_split(a, nprod, 0, stream));
+    if (nprod) HIP_TRY(h, launch_gemm_split(a, nprod, split_tile_for(h, M, N, K, split_k, epilogue), stream));
     else HIP_TRY(h, launch_gemm_f32(a, 0, stream));
     return ASR_OK;
 }
