@@ -1,9 +1,10 @@
-"""One-off diagnostic (GPU box): decode bench.py's 64-utterance batch in every precision mode and with the CPU oracle
+"""(Test infrastructure, not collected by pytest: it imports the CPU oracle, which only tests/, bench.py's CPU leg and smoke() may.)
+One-off diagnostic (GPU box): decode bench.py's 64-utterance batch in every precision mode and with the CPU oracle
 (float32, K/V-cache algorithm, and float64 on the utterances where anything differs), and say per mode how many
 utterances are token-identical to the oracle and where the first difference lies.  Random-init weights over 201 steps
 leave near-ties; this tells a near-tie from a defect.
 
-    python tools/check_modes.py [n_utts] > gpurun_out/check_modes.json
+    python tests/diag_check_modes.py [n_utts] > gpurun_out/check_modes.json
 """
 import json
 import os

@@ -1,9 +1,10 @@
-"""Diagnostic (GPU box): for single utterances of bench.py's batch, find the first decode step at which a precision
+"""(Test infrastructure, not collected by pytest: it imports the CPU oracle, which only tests/, bench.py's CPU leg and smoke() may.)
+Diagnostic (GPU box): for single utterances of bench.py's batch, find the first decode step at which a precision
 mode's (tokens, parents) leave the float64 oracle's, and print how close the oracle's own candidates are there: the gap
 between neighbouring totals around the pruning boundary, against the error of the GPU's candidate scores on the steps
 before.  A gap below that error is a near-tie (either answer is as good); a gap far above it is a defect.
 
-    python tools/near_tie.py 4 14 > gpurun_out/near_tie.json
+    python tests/diag_near_tie.py 4 14 > gpurun_out/near_tie.json
 """
 import json
 import os
