@@ -105,6 +105,7 @@ struct asr_handle {
     // so that the launch gaps and tails of one half's kernels are filled by the other's (ASR_AMD_SUBBATCH=1 disables)
     hipStream_t xstream[3] = {nullptr, nullptr, nullptr};   // streams of sub-batches 1..3 (sub-batch 0 runs on `stream`)
     hipEvent_t fork_ev = nullptr;
+    std::string twice;                  // ASR_AMD_DOUBLE (measurement aid): decode kernel class that is launched twice
     bool shared_gpu = false;            // asr_config.shared_gpu: other handles keep the GPU busy, prefer fewer K-slices
     int use_graph = -1;                 // steps 2.. of the beam search replayed from a captured HIP graph: 1 always, 0 never,
                                         // -1 from 320 beam rows up (the sub-batch regime, where the host issues 100 000 launches a
@@ -275,6 +276,11 @@ inline int split_tile_for(const asr_handle* h, int M, int N, int K, int split_k,
     return (t == 6 && h->shared_gpu) ? 9 : t;
 }
 
+// Measurement aid (ASR_AMD_DOUBLE=glu|proj|qkv|ffn2|logits|self|cross|ln): the decode-step kernels of that class are launched
+// twice - every one of them is idempotent (same inputs, same outputs) - so the change in step time is what that class costs
+// with everything else as it is (the costs add up to the step).  1 launch when unset.
+inline int launches_of(const asr_handle* h, const char* cls) { return (!h->twice.empty() && h->twice == cls) ? 2 : 1; }
+
 const char* gemm_class_name(const asr_handle* h, int nprod, int M, int N, int K, int epilogue, int split_k)
 {
     static std::map<std::string, std::string> interned;           // stable c_str() for ProfClass::name
@@ -308,6 +314,10 @@ int gemm(asr_handle* h, const float* A, const float* W, const float* bias, float
     const double wbytes = nprod ? 2.0 * gemm_split_planes(nprod) : 4.0;
     ProfScope ps(h, h->profile ? gemm_class_name(h, nprod, M, N, K, epilogue, split_k) : "", 2.0 * M * N * (double)K,
                  4.0 * ((double)M * K + (double)M * nout) + wbytes * (double)N * K, stream);
+    const char* cls = M > 4096 ? "" : epilogue == EPI_GLU ? "glu" : K == h->F ? "ffn2" : N == 3 * h->H ? "qkv" : N == h->V ? "logits" :
+                      (N == h->H && K == h->H) ? "proj" : "";
+    for (int rep = launches_of(h, cls); rep > 1; --rep)
+        if (nprod) HIP_TRY(h, launch_gemm_split(a, nprod, split_tile_for(h, M, N, K, split_k, epilogue), stream));
     if (nprod) HIP_TRY(h, launch_gemm_split(a, nprod, split_tile_for(h, M, N, K, split_k, epilogue), stream));
     else HIP_TRY(h, launch_gemm_f32(a, 0, stream));
     return ASR_OK;
@@ -720,13 +730,13 @@ int step_attention_half(asr_handle* h, const DecView& v, const StepCtx& c, int l
         // bytes here: the q/k/v slabs in, the new K/V rows and the context out; the history it streams (the utterances'
         // LIVE rows) is added by decode_core from the live counts of the steps that ran
         ProfScope ps(h, "decoder_self_attention", 0, 4.0 * R * 3.0 * H * c.s_qkv + 2.0 * R * H * (double)esz + 4.0 * R * H, s);
-        HIP_TRY(h, launch_decoder_self_attention(a, s));
+        for (int rep = launches_of(h, "self"); rep > 0; --rep) HIP_TRY(h, launch_decoder_self_attention(a, s));
     }
     rc = gemm(h, v.dctx, b.wo, nullptr, v.part, R, H, H, EPI_PARTIAL, c.s_proj, s);
     if (rc) return rc;
     {
         ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + c.s_proj), s);
-        HIP_TRY(h, launch_add_layer_norm_done(v.y0, v.part, c.s_proj, RH, b.bo, b.ln0s, b.ln0b, nullptr, nullptr, R, H,
+        for (int rep = launches_of(h, "ln"); rep > 0; --rep) HIP_TRY(h, launch_add_layer_norm_done(v.y0, v.part, c.s_proj, RH, b.bo, b.ln0s, b.ln0b, nullptr, nullptr, R, H,
                                               v.z1, st.done, s));
     }
     rc = gemm(h, v.z1, b.wq, nullptr, v.part, R, H, H, EPI_PARTIAL, c.s_proj, s);
@@ -740,13 +750,13 @@ int step_attention_half(asr_handle* h, const DecView& v, const StepCtx& c, int l
         a.pad2 = v.pad2; a.done = st.done;
         a.ctx = v.dctx; a.b = n; a.k = K; a.heads = h->heads; a.t = t;
         ProfScope ps(h, "decoder_cross_attention", 4.0 * R * (double)t * H, (h->kv_bf16 ? 2.0 : 4.0) * 2.0 * n * (double)t * H, s);
-        HIP_TRY(h, launch_decoder_cross_attention(a, s));
+        for (int rep = launches_of(h, "cross"); rep > 0; --rep) HIP_TRY(h, launch_decoder_cross_attention(a, s));
     }
     rc = gemm(h, v.dctx, b.wco, nullptr, v.part, R, H, H, EPI_PARTIAL, c.s_proj, s);
     if (rc) return rc;
     {
         ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + c.s_proj), s);
-        HIP_TRY(h, launch_add_layer_norm_done(v.z1, v.part, c.s_proj, RH, b.bco, b.ln1s, b.ln1b, nullptr, nullptr, R, H,
+        for (int rep = launches_of(h, "ln"); rep > 0; --rep) HIP_TRY(h, launch_add_layer_norm_done(v.z1, v.part, c.s_proj, RH, b.bco, b.ln1s, b.ln1b, nullptr, nullptr, R, H,
                                               v.z2, st.done, s));
     }
     return ASR_OK;
@@ -763,7 +773,7 @@ int step_ffn_half(asr_handle* h, const DecView& v, const StepCtx& c, int l)
     rc = gemm(h, v.dhid, b.w2, nullptr, v.part, R, H, F, EPI_PARTIAL, c.s_ffn2, s);
     if (rc) return rc;
     ProfScope ps(h, "add_layer_norm(dec)", 0, 4.0 * R * H * (2.0 + c.s_ffn2), s);
-    HIP_TRY(h, launch_add_layer_norm_done(v.z2, v.part, c.s_ffn2, c.RH, b.b2, b.ln2s, b.ln2b, nullptr, nullptr, R, H,
+    for (int rep = launches_of(h, "ln"); rep > 0; --rep) HIP_TRY(h, launch_add_layer_norm_done(v.z2, v.part, c.s_ffn2, c.RH, b.b2, b.ln2s, b.ln2b, nullptr, nullptr, R, H,
                                           v.y0, v.beam.done, s));
     return ASR_OK;
 }
@@ -1165,6 +1175,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     //  queues - 4 by default - and streams share them in creation order, so a handle that runs whole batches should hold one)
     if ((e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     h->shared_gpu = cfg->shared_gpu != 0;
+    if (const char* tw = getenv("ASR_AMD_DOUBLE")) h->twice = tw;
     if (cfg->sub_batches) h->sub_batches = cfg->sub_batches;
     else if (const char* sb = getenv("ASR_AMD_SUBBATCH")) h->sub_batches = std::max(0, std::min(MAX_VIEWS, atoi(sb)));
     if (const char* gr = getenv("ASR_AMD_GRAPH")) h->use_graph = atoi(gr) != 0 ? 1 : 0;
