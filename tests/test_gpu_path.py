@@ -159,6 +159,29 @@ def test_graph_replay_of_the_decode_step_gives_the_same_hypotheses(monkeypatch):
             eng.close()
 
 
+@pytest.mark.parametrize('cls', ['glu', 'proj', 'qkv', 'ffn2', 'logits', 'self', 'cross', 'ln'])
+def test_launching_a_kernel_class_twice_changes_nothing(monkeypatch, cls):
+    """ASR_AMD_DOUBLE (measurement aid, tools/marginal_cost.sh): every decode kernel of the class is launched twice; each is
+    idempotent, so tokens, parents and logits of every step are bit-identical to a normal run."""
+    ocfg = tiny_config(beam_size=4, max_target_length=12)
+    W = O.random_weights(ocfg, seed=61, bias_scale=0.1)
+    X = tiny_inputs((75, 40, 90), seed=62)
+    monkeypatch.delenv('ASR_AMD_DOUBLE', raising=False)
+    ref = _engine(ocfg, W, sub_batches=1)
+    monkeypatch.setenv('ASR_AMD_DOUBLE', cls)
+    twice = _engine(ocfg, W, sub_batches=1)
+    try:
+        Ya, ta = ref.decode_trace(X, 13)
+        Yb, tb = twice.decode_trace(X, 13)
+        assert np.array_equal(Ya, Yb)
+        for s in range(len(ta['tokens'])):
+            assert np.array_equal(ta['tokens'][s], tb['tokens'][s]) and np.array_equal(ta['parents'][s], tb['parents'][s])
+            assert np.array_equal(ta['logits'][s], tb['logits'][s])
+    finally:
+        ref.close()
+        twice.close()
+
+
 def test_profile_modes_bracket_every_launch_and_leave_the_hypotheses_alone():
     """asr_set_profile 1 (every bracket waited for) and 2 (brackets left in the two queues): the same classes and launch
     counts, times > 0, the same hypotheses as an unprofiled call; self-attention's bytes are the live rows streamed."""
