@@ -276,7 +276,7 @@ inline int split_tile_for(const asr_handle* h, int M, int N, int K, int split_k,
     return (t == 6 && h->shared_gpu) ? 9 : t;
 }
 
-// Measurement aid (ASR_AMD_DOUBLE=glu|proj|qkv|ffn2|logits|self|cross|ln): the decode-step kernels of that class are launched
+// Measurement aid (ASR_AMD_DOUBLE=glu|proj|qkv|ffn2|logits|self|cross|ln|topk|encoder): the decode-step kernels of that class are launched
 // twice - every one of them is idempotent (same inputs, same outputs) - so the change in step time is what that class costs
 // with everything else as it is (the costs add up to the step).  1 launch when unset.
 inline int launches_of(const asr_handle* h, const char* cls) { return (!h->twice.empty() && h->twice == cls) ? 2 : 1; }
@@ -789,7 +789,8 @@ int step_tail(asr_handle* h, const DecView& v, const StepCtx& c)
     if (rc) return rc;
     {
         ProfScope ps(h, "log_softmax_topk", 0, 4.0 * R * (double)h->V * s_log, s);
-        HIP_TRY(h, launch_log_softmax_topk(v.logits, s_log, (size_t)R * h->V, R, h->V, K, v.cand_scores, v.cand_tokens, st.done, s));   // :345-346
+        for (int rep = launches_of(h, "topk"); rep > 0; --rep)
+            HIP_TRY(h, launch_log_softmax_topk(v.logits, s_log, (size_t)R * h->V, R, h->V, K, v.cand_scores, v.cand_tokens, st.done, s));   // :345-346
     }
     {
         ProfScope ps(h, "beam_step", 0, 4.0 * R * H * 3.0, s);          // embedding row + timing row in, next decoder input out
@@ -901,10 +902,12 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     if (n == 0) { *len_out = 0; return ASR_OK; }                                                    // model.py:184-187
     int rc = ensure_decoder_capacity(h, n);
     if (rc) return rc;
-    rc = run_encoder(h, X_dev, n, t);
-    if (rc) return rc;
-    rc = run_cross_kv(h, n, t);
-    if (rc) return rc;
+    for (int rep = launches_of(h, "encoder"); rep > 0; --rep) {     // (encoder + cross K/V of the batch: idempotent as a whole)
+        rc = run_encoder(h, X_dev, n, t);
+        if (rc) return rc;
+        rc = run_cross_kv(h, n, t);
+        if (rc) return rc;
+    }
     const int K = h->K, R = n * K;
     h->beam.limit = std::min(t + 50, (int)h->cfg.max_target_length);                                // :310 (Q7)
     const int max_steps = h->beam.limit + 1;

@@ -159,7 +159,7 @@ def test_graph_replay_of_the_decode_step_gives_the_same_hypotheses(monkeypatch):
             eng.close()
 
 
-@pytest.mark.parametrize('cls', ['glu', 'proj', 'qkv', 'ffn2', 'logits', 'self', 'cross', 'ln'])
+@pytest.mark.parametrize('cls', ['glu', 'proj', 'qkv', 'ffn2', 'logits', 'self', 'cross', 'ln', 'topk', 'encoder'])
 def test_launching_a_kernel_class_twice_changes_nothing(monkeypatch, cls):
     """ASR_AMD_DOUBLE (measurement aid, tools/marginal_cost.sh): every decode kernel of the class is launched twice; each is
     idempotent, so tokens, parents and logits of every step are bit-identical to a normal run."""
