@@ -88,7 +88,8 @@ hipError_t launch_embed_shifted(const float* E, const int32_t* Y, int rows, int 
 // row_loss[r] = (Y[r] != 0) * (logsumexp(logits[r]) - logits[r][Y[r]])
 hipError_t launch_xent_rows(const float* logits, const int32_t* Y, int rows, int vocab, float* row_loss, hipStream_t s);
 // kv [n*t, 2*hidden] (k | v) -> k, v [n][heads][t][64], float32 or (kv_bf16) bf16 rounded to nearest even
-hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, void* k, void* v, int kv_bf16, hipStream_t s);
+// range_flag (may be null): set when a value does not fit fp16 (what the F16X3 attention kernels need)
+hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, void* k, void* v, int kv_bf16, int32_t* range_flag, hipStream_t s);
 // logits [nsplit][rows][vocab] split-K slabs (summed in slab order; nsplit = 1: plain logits)
 hipError_t launch_log_softmax_topk(const float* logits, int nsplit, size_t split_stride, int rows, int vocab, int k,
                                    float* values, int32_t* indices, const int32_t* done, hipStream_t s);
@@ -155,5 +156,7 @@ struct CrossAttnArgs {
     const int32_t* done;
     float* ctx;            // [R, hidden]
     int b, k, heads, t;
+    int f16x3;             // float32 K / V only: products as three fp16 MFMAs per multiply (operands must fit fp16's range)
+    int32_t* range_flag;   // f16x3: set when a q value does not fit (may be null); K / V are checked where they are written
 };
 hipError_t launch_decoder_cross_attention(const CrossAttnArgs& a, hipStream_t s);

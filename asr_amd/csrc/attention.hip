@@ -235,6 +235,28 @@ template <bool KV16> __device__ __forceinline__ void kv_unpack(const KvRegs<KV16
     }
 }
 
+// ---- float32 products on the fp16 matrix pipe, as gemm_split.hip does them (x = x1 + 2^-11 x2, x1 = fp16(x),
+// x2 = fp16(2^11 (x - x1)); a.b = a1 b1 + 2^-11 (a1 b2 + a2 b1) + O(2^-22)): the decode-time attention kernels' dot
+// products took a third of their time on the exact-f32 matrix instruction (1/16 of the fp16 rate) - matrix-pipe time the
+// GEMMs of the other steps in flight could not use.  Operands must fit fp16's range: the engine checks K / V rows where
+// they are written and q where it is assembled (range flag -> the call is repeated with the exact-f32 products).
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+constexpr float ATT_F16_SCALE = 2048.0f;
+__device__ __forceinline__ void split_f16x2(const f32x4& x, f16x4_t& hi, f16x4_t& lo)
+{
+    hi = __builtin_convertvector(x, f16x4_t);
+    lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x4)) * ATT_F16_SCALE, f16x4_t);
+}
+__device__ __forceinline__ f32x4 mfma16(const f16x4_t& a, const f16x4_t& b, const f32x4& c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bool fits_f16(const f32x4& x)
+{
+    const float m = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+    return m < 65504.0f;                                   // false for NaN as well
+}
+
 // ------------------------------------------------------------------------------------------------
 // Decoder self-attention at position `pos` (model.py:588-600 with reserve_last; no mask).
 // One workgroup per (utterance, head) serves all beams.  The beams' own k/v of position `pos` are
@@ -468,8 +490,8 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
 // Mask: -1e9 on padded encoder positions exactly as the reference (common_attention.py:202); keys
 // beyond t (block padding) get -inf.
 // ------------------------------------------------------------------------------------------------
-template <int NB, bool KV16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3 : 2)))
+template <int NB, bool KV16, bool F16X3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 && !F16X3 ? 3 : 2)))
 void decoder_cross_attention_kernel(CrossAttnArgs a)
 {
     if (*a.done) return;
@@ -496,6 +518,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
     }
 
     f32x4 qf[NB][4], qb[4];                                     // filled below, after the first block's loads are issued
+    f16x4_t qh[F16X3 ? NB : 1][4], ql[F16X3 ? NB : 1][4];       // F16X3: q as two fp16 terms
     const int nblk = (t + 15) >> 4;
     // two register sets, used alternately (no copies): the next block's loads fly under this block's MFMAs
     KvRegs<KV16> kv[2];
@@ -528,13 +551,34 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
                 for (int db = 0; db < 4; ++db) kc4[db] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        f16x4_t kh[4], kl[4], vh[4], vl[4];
+        if constexpr (F16X3) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) split_f16x2(kc4[db], kh[db], kl[db]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                       // tile j: V[key 4g + r][d = 4c + j], r = 0..3 (the MFMA's k = key)
+                const f32x4 tv = {vc4[0][j], vc4[1][j], vc4[2][j], vc4[3][j]};
+                split_f16x2(tv, vh[j], vl[j]);
+            }
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (F16X3) {
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
+                for (int db = 0; db < 4; ++db) {
+                    sc = mfma16(kh[db], ql[nb][db], sc);
+                    sc = mfma16(kl[db], qh[nb][db], sc);
+                    s = mfma16(kh[db], qh[nb][db], s);
+                }
+                s = s + sc * (1.0f / ATT_F16_SCALE);
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc4[db][j], qf[nb][db][j], s, 0, 0, 0);
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc4[db][j], qf[nb][db][j], s, 0, 0, 0);
+            }
             // s[r] = S[beam nb*16+c][key key0 + 4g + r]
             float mx = -INFINITY;
 #pragma unroll
@@ -550,10 +594,23 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
             m_run[nb] = m_new;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[nb][j] = o[nb][j] * alpha;
+            if constexpr (F16X3) {
+                f16x4_t ph, pl;
+                split_f16x2(s, ph, pl);                         // P^T[key 4g + r][beam c]: the B operand, k = key
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 tc = {0.f, 0.f, 0.f, 0.f};
+                    tc = mfma16(vh[j], pl, tc);
+                    tc = mfma16(vl[j], ph, tc);
+                    o[nb][j] = mfma16(vh[j], ph, o[nb][j]);
+                    o[nb][j] = o[nb][j] + tc * (1.0f / ATT_F16_SCALE);
+                }
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc4[r][j], s[r], o[nb][j], 0, 0, 0);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc4[r][j], s[r], o[nb][j], 0, 0, 0);
+            }
         }
     };
     using xc0 = std::integral_constant<int, 0>;
@@ -591,6 +648,10 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
             q4 = q4 * 0.125f;                                  // utils.py:628, after the bias (Q3)
             if (nb * 16 + c >= K) q4 = f32x4{0.f, 0.f, 0.f, 0.f};
             qf[nb][db] = q4;
+            if constexpr (F16X3) {
+                split_f16x2(q4, qh[nb][db], ql[nb][db]);
+                if (!fits_f16(q4) && a.range_flag) atomicOr(a.range_flag, 1);
+            }
         }
     }
 
@@ -692,11 +753,14 @@ hipError_t launch_decoder_cross_attention(const CrossAttnArgs& a, hipStream_t s)
     if (a.b <= 0) return hipSuccess;
     if (a.k > ASR_MAX_BEAM || a.k < 1 || a.t < 1) return hipErrorInvalidValue;
     if (a.kv_bf16) {
-        if (a.k <= 16) hipLaunchKernelGGL((decoder_cross_attention_kernel<1, true>), dim3(a.heads, a.b), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((decoder_cross_attention_kernel<2, true>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+        if (a.k <= 16) hipLaunchKernelGGL((decoder_cross_attention_kernel<1, true, false>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((decoder_cross_attention_kernel<2, true, false>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+    } else if (a.f16x3) {
+        if (a.k <= 16) hipLaunchKernelGGL((decoder_cross_attention_kernel<1, false, true>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((decoder_cross_attention_kernel<2, false, true>), dim3(a.heads, a.b), dim3(256), 0, s, a);
     } else {
-        if (a.k <= 16) hipLaunchKernelGGL((decoder_cross_attention_kernel<1, false>), dim3(a.heads, a.b), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((decoder_cross_attention_kernel<2, false>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+        if (a.k <= 16) hipLaunchKernelGGL((decoder_cross_attention_kernel<1, false, false>), dim3(a.heads, a.b), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((decoder_cross_attention_kernel<2, false, false>), dim3(a.heads, a.b), dim3(256), 0, s, a);
     }
     return hipGetLastError();
 }

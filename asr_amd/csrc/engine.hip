@@ -639,7 +639,8 @@ int run_cross_kv(asr_handle* h, int n, int t)
         int rc = gemm(h, h->x0, h->dec[l].wkv, h->dec[l].bkv, h->qkv, M, 2 * H, H, EPI_BIAS, 1);   // utils.py:618
         if (rc) return rc;
         ProfScope ps(h, "pack_cross_kv", 0, 4.0 * M * 4.0 * H);
-        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, h->heads, h->cross_k[l], h->cross_v[l], h->kv_bf16 ? 1 : 0, h->stream));
+        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, h->heads, h->cross_k[l], h->cross_v[l], h->kv_bf16 ? 1 : 0,
+                                        h->nprod_active == 13 ? h->range_flag : nullptr, h->stream));
     }
     return ASR_OK;
 }
@@ -747,6 +748,10 @@ int step_attention_half(asr_handle* h, const DecView& v, const StepCtx& c, int l
         const size_t esz = h->kv_bf16 ? 2 : 4;
         a.kc = reinterpret_cast<const char*>(h->cross_k[l]) + v.cross_off * esz; a.v = reinterpret_cast<const char*>(h->cross_v[l]) + v.cross_off * esz;
         a.kv_bf16 = h->kv_bf16 ? 1 : 0;
+        // default mode: the attention products on the fp16 matrix pipe like the GEMMs' (three per multiply); a repeated call
+        // (nprod_active 6) and the other modes keep the exact-f32 matrix instruction
+        a.f16x3 = (h->nprod_active == 13 && !h->kv_bf16) ? 1 : 0;
+        a.range_flag = a.f16x3 ? h->range_flag : nullptr;
         a.pad2 = v.pad2; a.done = st.done;
         a.ctx = v.dctx; a.b = n; a.k = K; a.heads = h->heads; a.t = t;
         ProfScope ps(h, "decoder_cross_attention", 4.0 * R * (double)t * H, (h->kv_bf16 ? 2.0 : 4.0) * 2.0 * n * (double)t * H, s);
@@ -1710,7 +1715,7 @@ int asr_op_pack_cross_kv(asr_handle* h, const float* kv, int32_t n, int32_t t, i
     HIP_TRY(h, tb.up(&dkv, kv, cnt * 2, s));
     HIP_TRY(h, tb.up<char>(&dk, nullptr, cnt * esz, s));
     HIP_TRY(h, tb.up<char>(&dv, nullptr, cnt * esz, s));
-    HIP_TRY(h, launch_pack_cross_kv(dkv, n, t, heads, dk, dv, as_bf16 ? 1 : 0, s));
+    HIP_TRY(h, launch_pack_cross_kv(dkv, n, t, heads, dk, dv, as_bf16 ? 1 : 0, nullptr, s));
     HIP_TRY(h, hipMemcpyAsync(k, dk, cnt * esz, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(v, dv, cnt * esz, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));

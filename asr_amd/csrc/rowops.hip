@@ -351,8 +351,10 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
 // (utterance, head) workgroup of the decode-time cross-attention streams two contiguous arrays) ----
 template <bool KV16>
 __global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restrict__ kv, int t, int heads,
-                                                             void* __restrict__ kout, void* __restrict__ vout)
+                                                             void* __restrict__ kout, void* __restrict__ vout,
+                                                             int32_t* __restrict__ range_flag)
 {
+    bool fits = true;                                          // every value below fp16's largest (attention.hip F16X3)
     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     const int t0 = blockIdx.x * 64, h = blockIdx.y, u = blockIdx.z;
@@ -363,6 +365,8 @@ __global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restr
             const float* row = kv + ((size_t)u * t + t0 + tt) * (2 * hidden);
             const size_t o = (((size_t)u * heads + h) * t + t0 + tt) * 64;
             const f32x4 k4 = reinterpret_cast<const f32x4*>(row + h * 64)[c], v4 = reinterpret_cast<const f32x4*>(row + hidden + h * 64)[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fits = fits && fabsf(k4[e]) < 65504.0f && fabsf(v4[e]) < 65504.0f;   // (false for NaN)
             if constexpr (KV16) {
                 reinterpret_cast<u32x2_t*>(static_cast<uint16_t*>(kout) + o)[c] = __builtin_bit_cast(u32x2_t, __builtin_convertvector(k4, bf16x4_t));
                 reinterpret_cast<u32x2_t*>(static_cast<uint16_t*>(vout) + o)[c] = __builtin_bit_cast(u32x2_t, __builtin_convertvector(v4, bf16x4_t));
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(256) void pack_cross_kv_kernel(const float* __restr
             }
         }
     }
+    if (!fits && range_flag) atomicOr(range_flag, 1);
 }
 
 // A logit that is NaN or infinite (garbage in: NaN features, an overflowed layer) must not reach the selection code:
@@ -823,11 +828,11 @@ hipError_t launch_xent_rows(const float* logits, const int32_t* Y, int rows, int
     return hipGetLastError();
 }
 
-hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, void* k, void* v, int kv_bf16, hipStream_t s)
+hipError_t launch_pack_cross_kv(const float* kv, int n, int t, int heads, void* k, void* v, int kv_bf16, int32_t* range_flag, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    if (kv_bf16) hipLaunchKernelGGL(pack_cross_kv_kernel<true>, dim3((t + 63) / 64, heads, n), dim3(256), 0, s, kv, t, heads, k, v);
-    else hipLaunchKernelGGL(pack_cross_kv_kernel<false>, dim3((t + 63) / 64, heads, n), dim3(256), 0, s, kv, t, heads, k, v);
+    if (kv_bf16) hipLaunchKernelGGL(pack_cross_kv_kernel<true>, dim3((t + 63) / 64, heads, n), dim3(256), 0, s, kv, t, heads, k, v, range_flag);
+    else hipLaunchKernelGGL(pack_cross_kv_kernel<false>, dim3((t + 63) / 64, heads, n), dim3(256), 0, s, kv, t, heads, k, v, range_flag);
     return hipGetLastError();
 }
 

@@ -123,6 +123,41 @@ def test_f16x3_decode_with_out_of_range_features_matches_oracle():
         eng.close()
 
 
+def test_f16x3_cross_attention_keys_outside_fp16_range_are_redone_with_exact_products():
+    """The default mode's decode-time cross-attention multiplies on the fp16 matrix pipe (three products per multiply, as its
+    GEMMs do).  Keys of magnitude >= 65504 (the K rows of kv_transform scaled up; every GEMM operand stays in range) are
+    caught where the K/V arrays are laid out: the call is repeated with the exact-f32 products and gives the oracle's
+    hypotheses."""
+    ocfg = tiny_config(beam_size=3, max_target_length=10)
+    W = dict(O.random_weights(ocfg, seed=4, bias_scale=0.1))
+    H = ocfg.hidden_units
+    for l in range(ocfg.num_blocks):
+        name = 'decoder/block_%d/decoder_vanilla_attention/kv_transform/kernel' % l
+        w = W[name].copy()
+        w[:H] *= np.float32(2.0e5)                                   # k = rows 0..H-1 (utils.py:618-619)
+        assert np.abs(w).max() < 65504.0                           # the weights themselves still fit fp16
+        W[name] = w
+    X = tiny_inputs((60, 90, 75), seed=14)
+    eng = _engine(ocfg, 'f32_f16x3', W)
+    try:
+        want = O.build_test_model(X, W, ocfg, num_gpus=1, algo='kv')
+        want64 = O.build_test_model(X.astype(np.float64), O.cast_weights(W, np.float64), ocfg, num_gpus=1, algo='kv')
+        assert np.array_equal(want, want64), 'near-tie in the oracle: pick another seed'
+        Y = eng.decode(X)
+        assert eng.range_retries() == 1
+        assert Y.shape == want.shape and np.array_equal(Y, want)
+        # and a batch that fits runs on the fp16 products without a repeat
+        W2 = O.random_weights(ocfg, seed=4, bias_scale=0.1)
+        eng2 = _engine(ocfg, 'f32_f16x3', W2)
+        try:
+            assert np.array_equal(eng2.decode(X), O.build_test_model(X, W2, ocfg, num_gpus=1, algo='kv'))
+            assert eng2.range_retries() == 0
+        finally:
+            eng2.close()
+    finally:
+        eng.close()
+
+
 def test_dense_glu_modes(mode_eng):
     from asr_amd import _lib as L
     mode, eng = mode_eng
