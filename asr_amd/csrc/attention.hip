@@ -257,6 +257,24 @@ __device__ __forceinline__ bool fits_f16(const f32x4& x)
     return m < 65504.0f;                                   // false for NaN as well
 }
 
+// ---- `precision: bf16`: K / V rows are bf16 already, so they go to the bf16 matrix instruction as they are loaded (no
+// widening, 1/16 of the exact-f32 instruction's passes); the float32 side of each product (q, P) goes in as two bf16 terms
+// (x = x1 + x2 to 16 significant bits, both in float32's exponent range: no scaling and no range guard).
+__device__ __forceinline__ void split_bf16x2(const f32x4& x, bf16x4_t& hi, bf16x4_t& lo)
+{
+    hi = __builtin_convertvector(x, bf16x4_t);
+    lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), bf16x4_t);
+}
+__device__ __forceinline__ f32x4 mfma16(const bf16x4_t& a, const bf16x4_t& b, const f32x4& c)
+{
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4_t bf16x4_of(uint32_t w0, uint32_t w1)
+{
+    return __builtin_bit_cast(bf16x4_t, u32x2_t{w0, w1});
+}
+
 // ------------------------------------------------------------------------------------------------
 // Decoder self-attention at position `pos` (model.py:588-600 with reserve_last; no mask).
 // One workgroup per (utterance, head) serves all beams.  The beams' own k/v of position `pos` are
@@ -519,6 +537,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
 
     f32x4 qf[NB][4], qb[4];                                     // filled below, after the first block's loads are issued
     f16x4_t qh[F16X3 ? NB : 1][4], ql[F16X3 ? NB : 1][4];       // F16X3: q as two fp16 terms
+    bf16x4_t qbh[KV16 ? NB : 1][4], qbl[KV16 ? NB : 1][4];      // KV16: q as two bf16 terms
     const int nblk = (t + 15) >> 4;
     // two register sets, used alternately (no copies): the next block's loads fly under this block's MFMAs
     KvRegs<KV16> kv[2];
@@ -536,7 +555,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
     auto compute_block = [&](auto setc, int blk) {
         constexpr int S = decltype(setc)::value;
         f32x4 kc4[4], vc4[4];
-        kv_unpack<KV16>(kv[S], kc4, vc4);
+        KvRegs<KV16> kr = kv[S];
         float bc[4];
         const int keyq = blk * 16 + 4 * g;
 #pragma unroll
@@ -545,11 +564,24 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
             // spare rows past t hold whatever was there (possibly NaN): an -inf score alone would leave 0 x NaN in P.V
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (keyq + i >= t) vc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (keyq + i >= t) kr.v[i] = {};
             if (blk * 16 + c >= t) {
 #pragma unroll
-                for (int db = 0; db < 4; ++db) kc4[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int db = 0; db < (KV16 ? 2 : 4); ++db) kr.k[db] = {};
             }
+        }
+        bf16x4_t kb[4], vb[4];
+        if constexpr (KV16) {
+            // K fragments in kv_d_of order; V tile j = V[key 4g + r][d = 4c + j], r = 0..3: the 16-bit halves of four rows
+            kb[0] = bf16x4_of(kr.k[0][0], kr.k[0][1]); kb[1] = bf16x4_of(kr.k[0][2], kr.k[0][3]);
+            kb[2] = bf16x4_of(kr.k[1][0], kr.k[1][1]); kb[3] = bf16x4_of(kr.k[1][2], kr.k[1][3]);
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                vb[2 * w] = bf16x4_of((kr.v[0][w] & 0xffffu) | (kr.v[1][w] << 16), (kr.v[2][w] & 0xffffu) | (kr.v[3][w] << 16));
+                vb[2 * w + 1] = bf16x4_of((kr.v[0][w] >> 16) | (kr.v[1][w] & 0xffff0000u), (kr.v[2][w] >> 16) | (kr.v[3][w] & 0xffff0000u));
+            }
+        } else {
+            kv_unpack<KV16>(kr, kc4, vc4);
         }
         f16x4_t kh[4], kl[4], vh[4], vl[4];
         if constexpr (F16X3) {
@@ -573,6 +605,12 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
                     s = mfma16(kh[db], qh[nb][db], s);
                 }
                 s = s + sc * (1.0f / ATT_F16_SCALE);
+            } else if constexpr (KV16) {
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    s = mfma16(kb[db], qbl[nb][db], s);         // small terms first
+                    s = mfma16(kb[db], qbh[nb][db], s);
+                }
             } else {
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
@@ -604,6 +642,14 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
                     tc = mfma16(vl[j], ph, tc);
                     o[nb][j] = mfma16(vh[j], ph, o[nb][j]);
                     o[nb][j] = o[nb][j] + tc * (1.0f / ATT_F16_SCALE);
+                }
+            } else if constexpr (KV16) {
+                bf16x4_t pbh, pbl;
+                split_bf16x2(s, pbh, pbl);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[nb][j] = mfma16(vb[j], pbl, o[nb][j]);
+                    o[nb][j] = mfma16(vb[j], pbh, o[nb][j]);
                 }
             } else {
 #pragma unroll
@@ -652,6 +698,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
                 split_f16x2(q4, qh[nb][db], ql[nb][db]);
                 if (!fits_f16(q4) && a.range_flag) atomicOr(a.range_flag, 1);
             }
+            if constexpr (KV16) split_bf16x2(q4, qbh[nb][db], qbl[nb][db]);
         }
     }
 
