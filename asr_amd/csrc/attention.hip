@@ -170,8 +170,9 @@ __device__ __forceinline__ float exp_neg(float x)
 
 // ---- K/V storage of the decode-time attention kernels ---------------------------------------------------------
 // KV16 = false: float32 rows (every float32 precision mode).  KV16 = true (`precision: bf16` only): the caches hold bf16
-// (round to nearest even when a row is written), half the bytes of the HBM-bound key loop; scores, soft-max and P.V stay
-// in float32 on the exact-f32 MFMA, bf16 values are widened exactly.  A lane's 16 K values of one key are, in both
+// (round to nearest even when a row is written), half the bytes of the HBM-bound key loop; the rows go to the bf16 matrix
+// instruction as loaded, q and P as two bf16 terms each (16 significant bits), accumulation, scores and soft-max in
+// float32 (kv_frags_bf16 / split_bf16x2 below).  A lane's 16 K values of one key are, in both
 // modes, 16-byte loads: float32 4 x (4 consecutive d at 16 q + 4 g), bf16 2 x (8 consecutive d at 32 (q / 2) + 8 g);
 // the MFMA's k index is only a summation label, so q fragments simply follow the same order (kv_d_of).
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -274,6 +275,17 @@ __device__ __forceinline__ bf16x4_t bf16x4_of(uint32_t w0, uint32_t w1)
 {
     return __builtin_bit_cast(bf16x4_t, u32x2_t{w0, w1});
 }
+// K fragments in kv_d_of order; V tile j = V[key 4g + r][d = 4c + j], r = 0..3: the 16-bit halves of four rows
+__device__ __forceinline__ void kv_frags_bf16(const KvRegs<true>& r, bf16x4_t (&kb)[4], bf16x4_t (&vb)[4])
+{
+    kb[0] = bf16x4_of(r.k[0][0], r.k[0][1]); kb[1] = bf16x4_of(r.k[0][2], r.k[0][3]);
+    kb[2] = bf16x4_of(r.k[1][0], r.k[1][1]); kb[3] = bf16x4_of(r.k[1][2], r.k[1][3]);
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        vb[2 * w] = bf16x4_of((r.v[0][w] & 0xffffu) | (r.v[1][w] << 16), (r.v[2][w] & 0xffffu) | (r.v[3][w] << 16));
+        vb[2 * w + 1] = bf16x4_of((r.v[0][w] >> 16) | (r.v[1][w] & 0xffff0000u), (r.v[2][w] >> 16) | (r.v[3][w] & 0xffff0000u));
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Decoder self-attention at position `pos` (model.py:588-600 with reserve_last; no mask).
@@ -358,6 +370,13 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int db = 0; db < 4; ++db) qf[nb][db] = *reinterpret_cast<const f32x4*>(qs + (nb * 16 + c) * 64 + kv_d_of<KV16>(db, g));
+    bf16x4_t qbh[KV16 ? NB : 1][4], qbl[KV16 ? NB : 1][4];
+    if constexpr (KV16) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) split_bf16x2(qf[nb][db], qbh[nb][db], qbl[nb][db]);
+    }
     float m_run[NB], l_run[NB];
     f32x4 o[NB][4];
 #pragma unroll
@@ -369,14 +388,24 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
 
     // one block of 16 keys: kc4 = K rows (lane: key c, d = db*16 + 4g ..), vc4 = V rows (lane: key 4g+r, d = 4c ..),
     // cj/cs = position (-1: the new position) and slot (-2: no such key) of key 4g+r
-    auto compute = [&](const f32x4 (&kc4)[4], const f32x4 (&vc4)[4], const int (&cj)[4], const int (&cs)[4]) {
+    // KV16: kop / vop are bf16 fragments (K in kv_d_of order; V tile j = V[key 4g + r][d = 4c + j], r = 0..3) for the bf16
+    // matrix instruction, q and P go in as two bf16 terms; otherwise float32 rows for the exact-f32 instruction
+    auto compute = [&](const auto (&kop)[4], const auto (&vop)[4], const int (&cj)[4], const int (&cs)[4]) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (KV16) {
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
+                for (int db = 0; db < 4; ++db) {
+                    s = mfma16(kop[db], qbl[nb][db], s);
+                    s = mfma16(kop[db], qbh[nb][db], s);
+                }
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kc4[db][j], qf[nb][db][j], s, 0, 0, 0);
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kop[db][j], qf[nb][db][j], s, 0, 0, 0);
+            }
             const int beam = nb * 16 + c, bl = min(beam, K - 1);
             float mx = -INFINITY;
 #pragma unroll
@@ -398,10 +427,20 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
             m_run[nb] = m_new;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[nb][j] = o[nb][j] * alpha;
+            if constexpr (KV16) {
+                bf16x4_t pbh, pbl;
+                split_bf16x2(s, pbh, pbl);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int j = 0; j < 4; ++j) {
+                    o[nb][j] = mfma16(vop[j], pbl, o[nb][j]);
+                    o[nb][j] = mfma16(vop[j], pbh, o[nb][j]);
+                }
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc4[r][j], s[r], o[nb][j], 0, 0, 0);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[nb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vop[r][j], s[r], o[nb][j], 0, 0, 0);
+            }
         }
     };
 
@@ -429,9 +468,15 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
     };
     auto compute_set = [&](auto setc) {
         constexpr int S = decltype(setc)::value;
-        f32x4 kc4[4], vc4[4];
-        kv_unpack<KV16>(kv[S], kc4, vc4);
-        compute(kc4, vc4, ej[S], es[S]);
+        if constexpr (KV16) {
+            bf16x4_t kb[4], vb[4];
+            kv_frags_bf16(kv[S], kb, vb);
+            compute(kb, vb, ej[S], es[S]);
+        } else {
+            f32x4 kc4[4], vc4[4];
+            kv_unpack<KV16>(kv[S], kc4, vc4);
+            compute(kc4, vc4, ej[S], es[S]);
+        }
     };
     using sc0 = std::integral_constant<int, 0>;
     using sc1 = std::integral_constant<int, 1>;
@@ -458,7 +503,17 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
                 cj[r] = -1;
                 cs[r] = kbm < K ? kbm : -2;
             }
-            compute(kc4, vc4, cj, cs);
+            if constexpr (KV16) {                              // rows in LDS hold the rounded values: the conversion is exact
+                bf16x4_t kb[4], vb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kb[j] = __builtin_convertvector(kc4[j], bf16x4_t);
+                    vb[j] = __builtin_convertvector(f32x4{vc4[0][j], vc4[1][j], vc4[2][j], vc4[3][j]}, bf16x4_t);
+                }
+                compute(kb, vb, cj, cs);
+            } else {
+                compute(kc4, vc4, cj, cs);
+            }
         }
     }
     __syncthreads();                                       // every wave is done with ancs / live: reuse as merge buffers
@@ -572,14 +627,7 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
         }
         bf16x4_t kb[4], vb[4];
         if constexpr (KV16) {
-            // K fragments in kv_d_of order; V tile j = V[key 4g + r][d = 4c + j], r = 0..3: the 16-bit halves of four rows
-            kb[0] = bf16x4_of(kr.k[0][0], kr.k[0][1]); kb[1] = bf16x4_of(kr.k[0][2], kr.k[0][3]);
-            kb[2] = bf16x4_of(kr.k[1][0], kr.k[1][1]); kb[3] = bf16x4_of(kr.k[1][2], kr.k[1][3]);
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                vb[2 * w] = bf16x4_of((kr.v[0][w] & 0xffffu) | (kr.v[1][w] << 16), (kr.v[2][w] & 0xffffu) | (kr.v[3][w] << 16));
-                vb[2 * w + 1] = bf16x4_of((kr.v[0][w] >> 16) | (kr.v[1][w] & 0xffff0000u), (kr.v[2][w] >> 16) | (kr.v[3][w] & 0xffff0000u));
-            }
+            kv_frags_bf16(kr, kb, vb);
         } else {
             kv_unpack<KV16>(kr, kc4, vc4);
         }
