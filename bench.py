@@ -66,7 +66,7 @@ PRECISION_INFO = {
     'f32_f16x3': ('f32 (every f32 operand split into 2 fp16 terms x1 + 2^-11 x2, 3 fp16 MFMA products per k-step in two f32 '
                   'accumulators: f32-chain accuracy)', 3, PEAK_BF16_MFMA_TFLOPS),
     'bf16x3': ('bf16x3 (2-term bf16 split, 3 MFMA products, f32 accumulate)', 3, PEAK_BF16_MFMA_TFLOPS),
-    'bf16': ('bf16 (f32 accumulate; attention, layer norms and beam search in f32)', 1, PEAK_BF16_MFMA_TFLOPS),
+    'bf16': ('bf16 (f32 accumulate; bf16 K/V caches, q and P as two bf16 terms; soft-max, layer norms and beam search in f32)', 1, PEAK_BF16_MFMA_TFLOPS),
 }
 MFMA_KERNELS = ('gemm', 'encoder_attention')          # classes priced against the matrix pipe; everything else against HBM
 
@@ -477,6 +477,27 @@ def main():
         if p1 and p1['ms'] > 0:
             rf['solo_avg_us'] = 1000.0 * p1['ms'] / p1['launches']
             rf['solo_frac'] = rf['frac'] * rf['avg_us'] / rf['solo_avg_us']
+        # The step as a whole (all kernel classes of ONE 64-utterance step, over the time a step takes in the timed
+        # region, i.e. with the other steps in flight sharing the chip): what the chip sustains, as opposed to what one
+        # kernel gets of it.  executed = algorithmic x the 16-bit products per multiply of the dense layers' kernels.
+        nprod_mode = PRECISION_INFO[args.precision][1]
+        step_s = 1e-3 * out['ms_per_step']                  # per GPU: every rank decodes a batch of its own per step
+        alg = sum(p['flops'] for p in prof if not p['name'].startswith('('))
+        exe = sum(p['flops'] * (nprod_mode if p['name'].startswith('gemm') else 1) for p in prof if not p['name'].startswith('('))
+        ws = {'algorithmic_tflop': alg / 1e12, 'algorithmic_tflops': alg / step_s / 1e12,
+              'executed_tflops': exe / step_s / 1e12, 'executed_frac_of_mfma_peak': exe / step_s / 1e12 / PRECISION_INFO[args.precision][2],
+              'algorithmic_gb': sum(p['bytes'] for p in prof if not p['name'].startswith('(')) / 1e9}
+        ws['algorithmic_gbs'] = ws['algorithmic_gb'] / step_s
+        ws['algorithmic_frac_of_hbm_peak'] = ws['algorithmic_gbs'] / PEAK_HBM_GBS
+        tr = [(measured_traffic(p['name'], args.precision) or measured_traffic(p['name'] + '_reg', args.precision), p['launches'])
+              for p in prof if not p['name'].startswith('(')]
+        if all(t is not None for t, _ in tr):
+            # memory-side traffic (PMC FETCH_SIZE / WRITE_SIZE per launch, profiles/): reads that missed the L2s, served by
+            # the Infinity Cache or by HBM
+            ws['pmc_traffic_gb'] = sum(t * l for t, l in tr) / 1e9
+            ws['pmc_traffic_gbs'] = ws['pmc_traffic_gb'] / step_s
+            ws['pmc_traffic_frac_of_hbm_peak'] = ws['pmc_traffic_gbs'] / PEAK_HBM_GBS
+        rf['whole_step'] = {k: round(v, 4) for k, v in ws.items()}
         if world == 1 and not args.no_cpu_baseline:
             cb, Yc = cpu_baseline(cfg, W, raw, min(args.cpu_sample_utts, n))
             m = min(Yc.shape[1], Y.shape[1])
