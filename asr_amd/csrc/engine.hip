@@ -1723,6 +1723,47 @@ int asr_op_pack_cross_kv(asr_handle* h, const float* kv, int32_t n, int32_t t, i
     return ASR_OK;
 }
 
+int asr_op_decoder_cross_attention(asr_handle* h, const float* q, const float* qbias, const float* kv, const int32_t* pad, int32_t n,
+                                   int32_t t, int32_t heads, int32_t beams, int32_t variant, float* ctx, int32_t* range_flag)
+{
+    if (!h || !q || !qbias || !kv || !pad || !ctx || n < 1 || t < 1 || heads < 1 || heads > 64 || beams < 1 || beams > ASR_MAX_BEAM ||
+        variant < 0 || variant > 2)
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    const size_t hidden = (size_t)heads * ASR_D_HEAD, rows = (size_t)n * t, cnt = rows * hidden, R = (size_t)n * beams;
+    const size_t esz = variant == 2 ? 2 : 4, slack = (size_t)ASR_XATT_SLACK_ROWS * 64;
+    TmpBufs tb;
+    float *dq, *db, *dkv, *dctx;
+    char *dk, *dv;
+    int32_t *dpad, *dflags;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, tb.up(&dq, q, R * hidden, s));
+    HIP_TRY(h, tb.up(&db, qbias, hidden, s));
+    HIP_TRY(h, tb.up(&dkv, kv, cnt * 2, s));
+    HIP_TRY(h, tb.up<char>(&dk, nullptr, (cnt + slack) * esz, s));
+    HIP_TRY(h, tb.up<char>(&dv, nullptr, (cnt + slack) * esz, s));
+    HIP_TRY(h, tb.up<int32_t>(&dpad, nullptr, rows + ASR_XATT_SLACK_ROWS, s));
+    HIP_TRY(h, tb.up<int32_t>(&dflags, nullptr, 2, s));                          // [0] done = 0, [1] range flag
+    HIP_TRY(h, tb.up<float>(&dctx, nullptr, R * hidden, s));
+    HIP_TRY(h, hipMemsetAsync(dflags, 0, 2 * sizeof(int32_t), s));
+    HIP_TRY(h, hipMemsetAsync(dpad, 0, (rows + ASR_XATT_SLACK_ROWS) * sizeof(int32_t), s));
+    HIP_TRY(h, hipMemcpyAsync(dpad, pad, rows * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, launch_pack_cross_kv(dkv, n, t, heads, dk, dv, variant == 2 ? 1 : 0, variant == 1 ? dflags + 1 : nullptr, s));
+    CrossAttnArgs a{};
+    a.qpart = dq; a.nsplit = 1; a.split_stride = 0; a.qbias = db;
+    a.kc = dk; a.v = dv; a.kv_bf16 = variant == 2 ? 1 : 0;
+    a.f16x3 = variant == 1 ? 1 : 0; a.range_flag = variant == 1 ? dflags + 1 : nullptr;
+    a.pad2 = dpad; a.done = dflags; a.ctx = dctx; a.b = n; a.k = beams; a.heads = heads; a.t = t;
+    HIP_TRY(h, launch_decoder_cross_attention(a, s));
+    int32_t flags[2] = {0, 0};
+    HIP_TRY(h, hipMemcpyAsync(ctx, dctx, R * hidden * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (range_flag) *range_flag = flags[1];
+    return ASR_OK;
+}
+
 int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, const float* beta, int32_t n, int32_t t, int32_t hidden,
                              float* y)
 {

@@ -204,6 +204,17 @@ int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, 
  * from two threads - race.  Blocks until y_dev is valid.  Results are bit-identical to asr_op_input_norm_timing. */
 int asr_op_input_norm_timing_noalloc(asr_handle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
                                      int32_t n, int32_t t, int32_t hidden, float* y_dev);
+/* Decode-time encoder-decoder attention core of one decoder block at one step (model.py:604-616 -> utils.py:612-631,
+ * common_attention.py:202 for the padding bias): q [n*beams, heads*64] = the query projection BEFORE its bias (qbias
+ * [heads*64] is added, then the 1/sqrt(64) scale of utils.py:628), kv [n*t, 2*heads*64] = the encoder-side (k | v)
+ * projection WITH its bias, pad [n*t] int32 (1 = padded position: -1e9 on its score) -> ctx [n*beams, heads*64]
+ * (combine_heads applied).  Runs the decode step's own kernels (pack_cross_kv + the cross-attention kernel) in the variant
+ * named: 0 = exact-float32 products, 1 = three fp16 products per multiply (the default mode's), 2 = K / V stored as
+ * bf16 (`precision: bf16`).  *range_flag (may be NULL) receives 1 when variant 1 met an operand outside fp16's range
+ * (the engine then repeats the call on variant 0; ctx is unspecified). */
+int asr_op_decoder_cross_attention(asr_handle* h, const float* q, const float* qbias, const float* kv, const int32_t* pad,
+                                   int32_t n, int32_t t, int32_t heads, int32_t beams, int32_t variant, float* ctx,
+                                   int32_t* range_flag);
 /* Encoder self-attention core (utils.py:624-631; common_attention.py:295-334): qkv [n,t,3*hidden]
  * (q | k | v, q NOT yet scaled), pad [n,t] int32 -> ctx [n,t,hidden]. */
 int asr_op_encoder_attention(asr_handle* h, const float* qkv, const int32_t* pad,

@@ -318,3 +318,69 @@ def test_pack_cross_kv_is_the_head_major_copy(L, eng, n, t, heads):
         u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
         return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
     assert np.array_equal(k16, bf16_rne(want_k)) and np.array_equal(v16, bf16_rne(want_v))
+
+
+def _bf16_round(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32).reshape(x.shape)
+
+
+@pytest.mark.parametrize('variant,tol', [(0, 2e-6), (1, 2e-6), (2, 3e-5)])
+@pytest.mark.parametrize('n,t,heads,beams', [(1, 1, 2, 1), (3, 37, 2, 10), (2, 334, 16, 10), (2, 100, 4, 20), (4, 16, 3, 16), (2, 1000, 2, 13)])
+def test_decoder_cross_attention_kernel_variants(L, eng, n, t, heads, beams, variant, tol):
+    """The decode-time encoder-decoder attention kernel alone (a8/a9: model.py:604-616 -> utils.py:612-631; -1e9 padding
+    bias of common_attention.py:202), all three variants the engine launches, against the float64 evaluation of the
+    oracle's expressions on the same operands: exact-f32 products and the default mode's three fp16 products per multiply
+    to the dense layers' bar (2e-6, max-abs / max-abs); the `precision: bf16` variant against the SAME float64 expressions
+    on K / V rounded to bf16 as its cache holds them - its own arithmetic adds only q and P at 16 significant bits (3e-5),
+    far below the mode's stated 5e-2.  Shapes: one key, ragged key counts around the 16-key blocks, two beam groups
+    (beams > 16), T = 1000 (config 5), padded positions incl. a whole padded tail.  Observed (max-abs / max-abs): exact f32
+    3e-7 .. 1e-6, fp16x3 3e-7 .. 5e-7, bf16 K/V 4e-6 .. 7e-6."""
+    H = heads * 64
+    rng = np.random.default_rng(1000 * n + t + beams + variant)
+    q = rng.standard_normal((n * beams, H)).astype(np.float32) * 2.0
+    qb = (rng.standard_normal(H) * 0.1).astype(np.float32)
+    kv = rng.standard_normal((n * t, 2 * H)).astype(np.float32)
+    pad = np.zeros((n, t), np.int32)
+    for u in range(n):
+        pad[u, t - (u * t) // (2 * n):] = 1                         # utterance u: a padded tail (none for u = 0)
+    if t > 5:
+        pad[n - 1, 2] = 1                                           # and one padded position in the middle
+    ctx = np.empty((n * beams, H), np.float32)
+    flag = np.zeros(1, np.int32)
+    L.check(eng._h, L.lib.asr_op_decoder_cross_attention(eng._h, L.fptr(q), L.fptr(qb), L.fptr(kv), L.iptr(pad.reshape(-1)), n, t, heads,
+                                                         beams, variant, L.fptr(ctx), L.iptr(flag)))
+    assert flag[0] == 0
+    kv_used = _bf16_round(kv) if variant == 2 else kv
+    k64 = O.split_heads(kv_used[:, :H].astype(np.float64).reshape(n, t, H), heads)
+    v64 = O.split_heads(kv_used[:, H:].astype(np.float64).reshape(n, t, H), heads)
+    q64 = O.split_heads((q.astype(np.float64) + qb.astype(np.float64)).reshape(n, beams, H), heads) * 64 ** -0.5
+    bias = (pad.astype(np.float64) * -1e9)[:, None, None, :]
+    want = O.combine_heads(O.dot_product_attention(q64, k64, v64, bias)).reshape(n * beams, H)
+    assert rel_err(ctx, want) < tol
+    # per-row reading of the same bar (rows with small outputs are not hidden behind the largest one)
+    row_err = np.abs(ctx - want).max(axis=1) / np.abs(want).max(axis=1)
+    assert row_err.max() < 10 * tol
+
+
+def test_decoder_cross_attention_f16x3_variant_reports_operands_outside_fp16_range(L, eng):
+    """Variant 1 multiplies fp16 pieces: a key (checked where K / V are laid out) or a query (checked where q is assembled)
+    beyond fp16's range must raise the flag the engine repeats the call on - never a silently wrong context."""
+    n, t, heads, beams = 2, 40, 2, 10
+    H = heads * 64
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((n * beams, H)).astype(np.float32)
+    qb = np.zeros(H, np.float32)
+    kv = rng.standard_normal((n * t, 2 * H)).astype(np.float32)
+    pad = np.zeros(n * t, np.int32)
+    ctx = np.empty((n * beams, H), np.float32)
+    for which in ('k', 'q'):
+        q2, kv2 = q.copy(), kv.copy()
+        if which == 'k':
+            kv2[17, 5] = 1.0e5
+        else:
+            q2[3, 70] = 9.0e5                                       # x 1/8 after the bias: still beyond 65504
+        flag = np.zeros(1, np.int32)
+        L.check(eng._h, L.lib.asr_op_decoder_cross_attention(eng._h, L.fptr(q2), L.fptr(qb), L.fptr(kv2), L.iptr(pad), n, t, heads, beams, 1,
+                                                             L.fptr(ctx), L.iptr(flag)))
+        assert flag[0] == 1, which
