@@ -1764,6 +1764,75 @@ int asr_op_decoder_cross_attention(asr_handle* h, const float* q, const float* q
     return ASR_OK;
 }
 
+int asr_op_decoder_self_attention(asr_handle* h, const float* qkv, const float* bias, const float* hist_k, const float* hist_v,
+                                  const int32_t* anc, int32_t n, int32_t pos, int32_t heads, int32_t beams, int32_t kv_bf16, float* ctx)
+{
+    if (!h || !qkv || !bias || !ctx || n < 1 || pos < 0 || pos > 4096 || heads < 1 || heads > 64 || beams < 1 || beams > ASR_MAX_BEAM ||
+        (pos > 0 && (!hist_k || !hist_v || !anc)))
+        return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    const int K = beams, width = std::max(pos + 1, 2);
+    const size_t hidden = (size_t)heads * ASR_D_HEAD, R = (size_t)n * K, esz = kv_bf16 ? 2 : 4;
+    if (self_attention_lds_bytes(K, width) > 150 * 1024) return fail(h, ASR_ERR_CAPACITY, "beams x positions beyond the kernel's LDS tables");
+    for (size_t i = 0; i < (size_t)n * K * pos; ++i)
+        if (anc[i] < 0 || anc[i] >= K) return fail(h, ASR_ERR_ARG, "ancestor slot outside [0, beams)");
+    int rc = set_device(h);
+    if (rc) return rc;
+    // host images of what the engine keeps on the device: head-major caches [n][heads][width][K][64], ancestry [n][K][width],
+    // live rows (position << 5 | slot) of each utterance = the (position, slot) pairs some beam's ancestry names
+    const size_t cache_elems = (size_t)n * heads * width * K * 64;
+    std::vector<char> kc(cache_elems * esz, 0), vc(cache_elems * esz, 0);
+    auto put = [&](std::vector<char>& dst, size_t idx, float x) {
+        if (kv_bf16) {
+            uint32_t u; memcpy(&u, &x, 4);
+            const uint16_t b = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);       // round to nearest even (finite inputs)
+            memcpy(&dst[idx * 2], &b, 2);
+        } else memcpy(&dst[idx * 4], &x, 4);
+    };
+    for (int u = 0; u < n; ++u)
+        for (int j = 0; j < pos; ++j)
+            for (int sl = 0; sl < K; ++sl)
+                for (int hd = 0; hd < heads; ++hd)
+                    for (int d = 0; d < 64; ++d) {
+                        const size_t src = (((size_t)u * pos + j) * K + sl) * hidden + hd * 64 + d;
+                        const size_t dst = ((((size_t)u * heads + hd) * width + j) * K + sl) * 64 + d;
+                        put(kc, dst, hist_k[src]); put(vc, dst, hist_v[src]);
+                    }
+    std::vector<int32_t> anc_w((size_t)n * K * width, 0), live((size_t)n * K * width, 0), live_cnt(n, 0);
+    for (int u = 0; u < n; ++u) {
+        std::vector<char> seen((size_t)std::max(pos, 1) * 32, 0);
+        for (int b = 0; b < K; ++b)
+            for (int j = 0; j < pos; ++j) {
+                const int sl = anc[((size_t)u * K + b) * pos + j];
+                anc_w[((size_t)u * K + b) * width + j] = sl;
+                if (!seen[(size_t)j * 32 + sl]) { seen[(size_t)j * 32 + sl] = 1; live[(size_t)u * K * width + live_cnt[u]++] = (j << 5) | sl; }
+            }
+    }
+    TmpBufs tb;
+    float *dqkv, *dbias, *dctx;
+    char *dk, *dv;
+    int32_t *danc, *dlive, *dcnt, *dflags;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, tb.up(&dqkv, qkv, R * 3 * hidden, s));
+    HIP_TRY(h, tb.up(&dbias, bias, 3 * hidden, s));
+    HIP_TRY(h, tb.up(&dk, kc.data(), kc.size(), s));
+    HIP_TRY(h, tb.up(&dv, vc.data(), vc.size(), s));
+    HIP_TRY(h, tb.up(&danc, anc_w.data(), anc_w.size(), s));
+    HIP_TRY(h, tb.up(&dlive, live.data(), live.size(), s));
+    HIP_TRY(h, tb.up(&dcnt, live_cnt.data(), live_cnt.size(), s));
+    const int32_t flags[2] = {pos, 0};                                            // [0] position, [1] done = 0
+    HIP_TRY(h, tb.up(&dflags, flags, 2, s));
+    HIP_TRY(h, tb.up<float>(&dctx, nullptr, R * hidden, s));
+    SelfAttnArgs a{};
+    a.qkv = dqkv; a.nsplit = 1; a.split_stride = 0; a.bias = dbias;
+    a.kcache = dk; a.vcache = dv; a.kv_bf16 = kv_bf16 ? 1 : 0;
+    a.anc0 = danc; a.anc1 = danc; a.live = dlive; a.live_cnt = dcnt; a.pos = dflags; a.done = dflags + 1;
+    a.ctx = dctx; a.b = n; a.k = K; a.heads = heads; a.width = width; a.lds_stride = width;
+    HIP_TRY(h, launch_decoder_self_attention(a, s));
+    HIP_TRY(h, hipMemcpyAsync(ctx, dctx, R * hidden * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ASR_OK;
+}
+
 int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, const float* beta, int32_t n, int32_t t, int32_t hidden,
                              float* y)
 {

@@ -215,6 +215,17 @@ int asr_op_input_norm_timing_noalloc(asr_handle* h, const float* x_dev, const fl
 int asr_op_decoder_cross_attention(asr_handle* h, const float* q, const float* qbias, const float* kv, const int32_t* pad,
                                    int32_t n, int32_t t, int32_t heads, int32_t beams, int32_t variant, float* ctx,
                                    int32_t* range_flag);
+/* Decode-time self-attention core of one decoder block at step `pos` (model.py:588-600 -> utils.py:612-631 with
+ * reserve_last, no bias): every beam attends over ITS OWN history and the new position.  qkv [n*beams, 3*heads*64] = the
+ * (q | k | v) projection of the new position BEFORE its bias (bias [3*heads*64] is added; q then scaled by 1/sqrt(64));
+ * hist_k / hist_v [n][pos][beams][heads*64] = the K / V rows written at earlier steps, by (position, beam slot);
+ * anc [n][beams][pos] = the slot of beam b's ancestor at position j (what the reference gets by gathering its cache with
+ * the surviving beams' indices, model.py:296-301; here rows never move).  -> ctx [n*beams, heads*64].  Builds the cache,
+ * the ancestry table and the list of live (position, slot) rows as the engine holds them and runs the decode step's own
+ * kernel; kv_bf16 = the `precision: bf16` variant (cache rows and the new rows rounded to bf16). pos may be 0. */
+int asr_op_decoder_self_attention(asr_handle* h, const float* qkv, const float* bias, const float* hist_k, const float* hist_v,
+                                  const int32_t* anc, int32_t n, int32_t pos, int32_t heads, int32_t beams, int32_t kv_bf16,
+                                  float* ctx);
 /* Encoder self-attention core (utils.py:624-631; common_attention.py:295-334): qkv [n,t,3*hidden]
  * (q | k | v, q NOT yet scaled), pad [n,t] int32 -> ctx [n,t,hidden]. */
 int asr_op_encoder_attention(asr_handle* h, const float* qkv, const int32_t* pad,

@@ -384,3 +384,54 @@ def test_decoder_cross_attention_f16x3_variant_reports_operands_outside_fp16_ran
         L.check(eng._h, L.lib.asr_op_decoder_cross_attention(eng._h, L.fptr(q2), L.fptr(qb), L.fptr(kv2), L.iptr(pad), n, t, heads, beams, 1,
                                                              L.fptr(ctx), L.iptr(flag)))
         assert flag[0] == 1, which
+
+
+@pytest.mark.parametrize('kv_bf16,tol', [(0, 2e-6), (1, 3e-5)])
+@pytest.mark.parametrize('n,pos,heads,beams', [(2, 0, 2, 10), (1, 1, 2, 1), (3, 7, 2, 10), (2, 40, 4, 10), (2, 33, 2, 20), (2, 199, 2, 10),
+                                               (1, 16, 3, 16)])
+def test_decoder_self_attention_kernel_variants(L, eng, n, pos, heads, beams, kv_bf16, tol):
+    """The decode-time self-attention kernel alone (a8/a9/a16: model.py:588-600, utils.py:612-631 with reserve_last) against
+    the float64 evaluation of the oracle's expressions, beam by beam over that beam's OWN history: the reference gathers
+    its cache with the surviving beams' indices at every step (model.py:296-301); the kernel leaves rows where they were
+    written and follows an ancestry table, streaming each LIVE (position, slot) row once for all beams - so the ancestry
+    here comes from simulated random survivor choices (beams share prefixes, some rows are dead).  float32 caches to the
+    dense layers' bar, the `precision: bf16` variant against the same expressions on rows rounded to bf16 as its cache
+    holds them (q and P at 16 significant bits on top: 3e-5).  Position 0 (no history), one beam, two beam groups
+    (beams > 16), 199 positions (the last step of max_target_length 200)."""
+    H, K = heads * 64, beams
+    rng = np.random.default_rng(100 * n + pos + beams + kv_bf16)
+    qkv = rng.standard_normal((n * K, 3 * H)).astype(np.float32)
+    qkv[:, :H] *= 2.0
+    bias = (rng.standard_normal(3 * H) * 0.1).astype(np.float32)
+    hk = rng.standard_normal((n, pos, K, H)).astype(np.float32)
+    hv = rng.standard_normal((n, pos, K, H)).astype(np.float32)
+    anc = np.zeros((n, K, pos), np.int32)
+    for u in range(n):
+        a = np.zeros((K, 0), np.int32)
+        for j in range(pos):
+            a = np.concatenate([a, np.arange(K, dtype=np.int32)[:, None]], axis=1)     # step j: beam b writes slot b ...
+            a = a[np.sort(rng.integers(0, max(1, K // 2 + 1), K))] if j % 3 else a[rng.integers(0, K, K)]   # ... survivors are chosen
+        anc[u] = a
+    ctx = np.empty((n * K, H), np.float32)
+    L.check(eng._h, L.lib.asr_op_decoder_self_attention(eng._h, L.fptr(qkv), L.fptr(bias), L.fptr(hk.reshape(-1)), L.fptr(hv.reshape(-1)),
+                                                        L.iptr(anc.reshape(-1)), n, pos, heads, K, kv_bf16, L.fptr(ctx)))
+    x = qkv + bias                                                  # float32, as the kernel adds it
+    rnd = _bf16_round if kv_bf16 else (lambda z: z)
+    q = x[:, :H].astype(np.float64).reshape(n, K, H) * 64 ** -0.5
+    kn = rnd(np.ascontiguousarray(x[:, H:2 * H])).astype(np.float64).reshape(n, K, H)
+    vn = rnd(np.ascontiguousarray(x[:, 2 * H:])).astype(np.float64).reshape(n, K, H)
+    hk64, hv64 = rnd(hk).astype(np.float64), rnd(hv).astype(np.float64)
+    want = np.empty((n, K, H))
+    jj = np.arange(pos)
+    for u in range(n):
+        for b in range(K):
+            keys = np.concatenate([hk64[u, jj, anc[u, b]], kn[u, b][None]], axis=0)          # [pos + 1, H]
+            vals = np.concatenate([hv64[u, jj, anc[u, b]], vn[u, b][None]], axis=0)
+            k4 = O.split_heads(keys[None], heads)
+            v4 = O.split_heads(vals[None], heads)
+            q4 = O.split_heads(q[u, b][None, None], heads)
+            want[u, b] = O.combine_heads(O.dot_product_attention(q4, k4, v4, None))[0, 0]
+    want = want.reshape(n * K, H)
+    assert rel_err(ctx, want) < tol
+    row_err = np.abs(ctx - want).max(axis=1) / np.abs(want).max(axis=1)
+    assert row_err.max() < 10 * tol
