@@ -279,6 +279,10 @@ class EnginePool(object):
                 cfg.test['sub_batches'] = 1
             if config.test.shared_gpu is None:
                 cfg.test['shared_gpu'] = 1
+        if n >= 4 and not os.environ.get('GPU_MAX_HW_QUEUES'):
+            # a handle per hardware queue (the runtime's default is four queues per process, and the streams of a fourth
+            # handle then share one).  Read by the HIP runtime when the process first touches the GPU: no effect later.
+            os.environ['GPU_MAX_HW_QUEUES'] = '8'
         self.engines = [Engine(cfg, device) for _ in range(n)]
 
     def load_weights(self, variables):
