@@ -85,6 +85,7 @@ def _load():
         'asr_op_input_norm_timing': (i32, [vp, f32p, f32p, f32p, i32, i32, i32, f32p]),
         'asr_op_embedding': (i32, [vp, f32p, i32p, i32, i32, i32, i32, i32, f32p]),
         'asr_op_pack_cross_kv': (i32, [vp, f32p, i32, i32, i32, i32, vp, vp]),
+        'asr_decode_groups': (i32, [vp, f32p, i32, i32p, i32p, i32, i32p, i64, i32p]),
         'asr_op_decoder_self_attention': (i32, [vp, f32p, f32p, f32p, f32p, i32p, i32, i32, i32, i32, i32, f32p]),
         'asr_op_decoder_cross_attention': (i32, [vp, f32p, f32p, f32p, i32p, i32, i32, i32, i32, i32, f32p, i32p]),
         'asr_op_input_norm_timing_noalloc': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),

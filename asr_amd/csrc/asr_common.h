@@ -109,6 +109,9 @@ struct BeamState {       // device pointers; double-buffered arrays are indexed 
     int32_t* parents;          // [R] last parents, global row index (trace)
     int width;                 // max_target_length + 2
     int limit;                 // min(T + 50, max_target_length)
+    const int32_t* limit_u;    // null, or [B]: utterance u's own limit (a joint decode of groups with different T): once
+                               // limit_u[u] + 1 steps are done the utterance's beams count as finished - they keep their
+                               // scores and are padded with 3, exactly what further steps do to finished beams
 };
 hipError_t launch_beam_init(const BeamState& st, int b, int k, hipStream_t s);
 // one pruning step + the next step's decoder input (y_next[r] = E[token r] * mult + pe[pos + 1]) + the loop condition
@@ -156,6 +159,9 @@ struct CrossAttnArgs {
     const int32_t* done;
     float* ctx;            // [R, hidden]
     int b, k, heads, t;
+    const int32_t* t_arr;  // null, or [b]: utterance u has t_arr[u] keys (a joint decode of groups with different t; `t` is then unused)
+    const int32_t* row_off;// with t_arr: [b] row index of utterance u's first key among all utterances' keys: its K / V are
+                           // [heads][t_arr[u]][64] at element row_off[u] * heads * 64, its padding flags at pad2 + row_off[u]
     int f16x3;             // float32 K / V only: products as three fp16 MFMAs per multiply (operands must fit fp16's range)
     int32_t* range_flag;   // f16x3: set when a q value does not fit (may be null); K / V are checked where they are written
 };

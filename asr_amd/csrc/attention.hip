@@ -573,14 +573,15 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
     const int h = blockIdx.x, u = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const int hidden = a.heads * 64, t = a.t, K = a.k;
+    const int hidden = a.heads * 64, t = a.t_arr ? a.t_arr[u] : a.t, K = a.k;
 
     // K and V of this (utterance, head) are two contiguous [t][64] arrays, so a 16-key block is 4 KB of each and every load
     // of a block is (per-lane base + block offset) + an immediate: no per-load address arithmetic.  The last block may run
     // past row t - 1: the engine allocates ASR_XATT_SLACK_ROWS spare rows behind K, V and the padding flags, and those keys
     // get -inf below.
-    const size_t kv_base = ((size_t)u * a.heads + h) * t * 64;                            // element index of key 0, d 0
-    const int32_t* pptr = a.pad2 + (size_t)u * t + 4 * g;                                 // key 4g (+ r)
+    const size_t key_row0 = a.t_arr ? (size_t)a.row_off[u] : (size_t)u * t;               // utterance's first key among all keys
+    const size_t kv_base = key_row0 * hidden + (size_t)h * t * 64;                        // element index of key 0, d 0
+    const int32_t* pptr = a.pad2 + key_row0 + 4 * g;                                      // key 4g (+ r)
     float m_run[NB], l_run[NB];
     f32x4 o[NB][4];
 #pragma unroll

@@ -66,6 +66,11 @@ struct asr_handle {
     int64_t range_retries = 0;          // calls repeated on the bf16x6 kernels so far
     bool weights_out_of_range = false;  // single-kernel probes: the caller's weight operand did not fit fp16
     bool kv_bf16 = false;               // precision bf16: K/V caches (self and cross) stored as bf16 (attention.hip KV16)
+    // a joint decode of groups with different T (asr_decode_groups), for the duration of the call: per-utterance key
+    // counts and first-key row offsets of the cross attention (device, [n]) and the keys of all utterances together
+    const int32_t* grp_t = nullptr;
+    const int32_t* grp_off = nullptr;
+    double grp_rows = 0.0;
     int logit_split = 1;                // K slices of the logits GEMM (their slabs are summed by the top-k kernel)
     float* emb_gemm = nullptr;          // logits operand when tied: = emb (f32 mode) or its bf16 planes
     hipStream_t stream = nullptr;
@@ -479,9 +484,10 @@ int upload_ffn1(asr_handle* h, const std::string& p, float** w, float** b)
 }
 
 // ---- workspaces -------------------------------------------------------------------------------
-int ensure_encoder_capacity(asr_handle* h, int n, int t)
+int ensure_encoder_rows(asr_handle* h, int n, size_t rows);
+int ensure_encoder_capacity(asr_handle* h, int n, int t) { return ensure_encoder_rows(h, n, (size_t)n * t); }
+int ensure_encoder_rows(asr_handle* h, int n, size_t rows)
 {
-    const size_t rows = (size_t)n * t;
     if (rows <= h->cap_rows && n <= h->cap_n) return ASR_OK;
     const size_t nrows = std::max(rows, h->cap_rows);
     const int nn = std::max(n, h->cap_n);
@@ -588,8 +594,9 @@ int ensure_decoder_capacity(asr_handle* h, int n)
 
 // ---- encoder (model.py:444-490) ----------------------------------------------------------------
 // X_dev [n, t, D] -> h->x0 [n*t, H] (encoder output), h->pad / h->pad2 [n*t]
-int run_encoder(asr_handle* h, const float* X_dev, int n, int t)
+int run_encoder(asr_handle* h, const float* X_dev, int n, int t, int32_t* pad2_dst = nullptr)
 {
+    if (!pad2_dst) pad2_dst = h->pad2;
     const int M = n * t, H = h->H, F = h->F;
     int rc = ensure_pe(h, std::max(t, h->cfg.max_target_length + 2));
     if (rc) return rc;
@@ -626,21 +633,23 @@ int run_encoder(asr_handle* h, const float* X_dev, int n, int t)
         {
             ProfScope ps(h, "add_layer_norm", 0, 4.0 * M * H * 3.0);
             HIP_TRY(h, launch_add_layer_norm(h->x3, h->x2, 1, 0, b.b2, b.ln1s, b.ln1b, last ? h->pad : nullptr,
-                                             last ? h->pad2 : nullptr, M, H, h->x0, s));            // model.py:481,489
+                                             last ? pad2_dst : nullptr, M, H, h->x0, s));           // model.py:481,489
         }
     }
     return ASR_OK;
 }
 
 // cross-attention K/V of every decoder block, once per utterance (instead of once per step per beam)
-int run_cross_kv(asr_handle* h, int n, int t)
+int run_cross_kv(asr_handle* h, int n, int t, size_t row_off = 0)
 {
     const int M = n * t, H = h->H;
+    const size_t boff = row_off * H * (h->kv_bf16 ? 2 : 4);           // bytes: this group's K / V start behind row_off rows
     for (int l = 0; l < h->L; ++l) {
         int rc = gemm(h, h->x0, h->dec[l].wkv, h->dec[l].bkv, h->qkv, M, 2 * H, H, EPI_BIAS, 1);   // utils.py:618
         if (rc) return rc;
         ProfScope ps(h, "pack_cross_kv", 0, 4.0 * M * 4.0 * H);
-        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, h->heads, h->cross_k[l], h->cross_v[l], h->kv_bf16 ? 1 : 0,
+        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, h->heads, reinterpret_cast<char*>(h->cross_k[l]) + boff,
+                                        reinterpret_cast<char*>(h->cross_v[l]) + boff, h->kv_bf16 ? 1 : 0,
                                         h->nprod_active == 13 ? h->range_flag : nullptr, h->stream));
     }
     return ASR_OK;
@@ -755,7 +764,9 @@ int step_attention_half(asr_handle* h, const DecView& v, const StepCtx& c, int l
         a.range_flag = a.f16x3 ? h->range_flag : nullptr;
         a.pad2 = v.pad2; a.done = st.done;
         a.ctx = v.dctx; a.b = n; a.k = K; a.heads = h->heads; a.t = t;
-        ProfScope ps(h, "decoder_cross_attention", 4.0 * R * (double)t * H, (h->kv_bf16 ? 2.0 : 4.0) * 2.0 * n * (double)t * H, s);
+        a.t_arr = h->grp_t; a.row_off = h->grp_off;
+        const double keys = h->grp_t ? h->grp_rows : (double)n * t;                       // keys of all utterances of the view
+        ProfScope ps(h, "decoder_cross_attention", 4.0 * K * keys * H, (h->kv_bf16 ? 2.0 : 4.0) * 2.0 * keys * H, s);
         for (int rep = launches_of(h, "cross"); rep > 0; --rep) HIP_TRY(h, launch_decoder_cross_attention(a, s));
     }
     rc = gemm(h, v.dctx, b.wco, nullptr, v.part, R, H, H, EPI_PARTIAL, c.s_proj, s);
@@ -901,20 +912,52 @@ void finalize_host(const int32_t* preds, const float* scores, int n, int K, int 
 struct TraceOut { int steps = 0; float* logits = nullptr; float* scores = nullptr; int32_t* tokens = nullptr; int32_t* parents = nullptr; };
 
 // X_dev [n,t,D] on device (already stacked) -> Y host
+// Groups of utterances padded to different T, decoded as ONE beam search (asr_decode_groups): X_dev holds group after group.
+struct Groups {
+    int count = 0;
+    const int32_t* n = nullptr;        // host [count]
+    const int32_t* t = nullptr;        // host [count]
+    const int32_t *d_t = nullptr, *d_off = nullptr, *d_limit = nullptr;     // device [sum n]: per utterance
+    int t_max = 0;
+    size_t rows = 0;                   // sum n[g] * t[g]
+};
+
 int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int64_t y_capacity, int32_t* len_out,
-                const TraceOut* tr)
+                const TraceOut* tr, const Groups* gr = nullptr)
 {
+    struct GroupScope {                // the handle's per-call group state never outlives the call
+        asr_handle* h;
+        ~GroupScope() { h->grp_t = h->grp_off = nullptr; h->grp_rows = 0.0; h->beam.limit_u = nullptr; }
+    } group_scope{h};
     if (!h->finalized) return fail(h, ASR_ERR_STATE, "asr_finalize_weights has not succeeded on this handle");
     if (n == 0) { *len_out = 0; return ASR_OK; }                                                    // model.py:184-187
     int rc = ensure_decoder_capacity(h, n);
     if (rc) return rc;
     for (int rep = launches_of(h, "encoder"); rep > 0; --rep) {     // (encoder + cross K/V of the batch: idempotent as a whole)
+        if (gr) {
+            // every group through the encoder with ITS T (the input layer norm runs over (T, H), model.py:453: T is part of
+            // the arithmetic), its cross K / V and padding flags laid out behind the groups before it
+            size_t row0 = 0;
+            for (int g = 0; g < gr->count; ++g) {
+                rc = run_encoder(h, X_dev + row0 * h->D, gr->n[g], gr->t[g], h->pad2 + row0);
+                if (rc) return rc;
+                rc = run_cross_kv(h, gr->n[g], gr->t[g], row0);
+                if (rc) return rc;
+                row0 += (size_t)gr->n[g] * gr->t[g];
+            }
+            continue;
+        }
         rc = run_encoder(h, X_dev, n, t);
         if (rc) return rc;
         rc = run_cross_kv(h, n, t);
         if (rc) return rc;
     }
     const int K = h->K, R = n * K;
+    if (gr) {
+        t = gr->t_max;                                              // the joint loop runs as long as the longest group's
+        h->grp_t = gr->d_t; h->grp_off = gr->d_off; h->grp_rows = (double)gr->rows;
+        h->beam.limit_u = gr->d_limit;
+    }
     h->beam.limit = std::min(t + 50, (int)h->cfg.max_target_length);                                // :310 (Q7)
     const int max_steps = h->beam.limit + 1;
     if (h->profile && !tr) {
@@ -934,7 +977,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     // when every utterance has finished: a half that ends earlier is padded with 3, which is what further steps
     // append to finished beams (model.py:253) without changing their order or scores.
     int nviews = h->sub_batches >= 2 ? std::min(h->sub_batches, n) : (h->sub_batches == 0 && R >= 320 ? 2 : 1);   // auto: each half still fills the GPU
-    if (tr) nviews = 1;                             // (profile mode keeps the parts: its brackets time the shapes the timed passes launch)
+    if (tr || gr) nviews = 1;                       // (profile mode keeps the parts: its brackets time the shapes the timed passes launch)
     DecView views[MAX_VIEWS];
     for (int vi = 0, n0 = 0; vi < nviews; ++vi) {   // the first n % nviews parts get one utterance more
         const int nv = n / nviews + (vi < n % nviews ? 1 : 0);
@@ -1400,6 +1443,57 @@ int asr_decode_trace(asr_handle* h, const float* X, int32_t n, int32_t t, int32_
 int asr_decode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d, int32_t* Y, int64_t y_capacity, int32_t* len_out)
 {
     return asr_decode_trace(h, X, n, t, d, Y, y_capacity, len_out, 0, nullptr, nullptr, nullptr, nullptr);
+}
+
+static int asr_decode_groups_once(asr_handle* h, const float* X, int32_t n_groups, const int32_t* n_g, const int32_t* t_g, int32_t d,
+                                  int32_t* Y, int64_t y_capacity, int32_t* len_out)
+{
+    if (!h || !len_out || !X || !Y || !n_g || !t_g || n_groups < 1 || n_groups > 4096)
+        return h ? fail(h, ASR_ERR_ARG, "null argument or group count outside 1..4096") : ASR_ERR_ARG;
+    int rc = set_device(h);
+    if (rc) return rc;
+    Groups gr;
+    gr.count = n_groups; gr.n = n_g; gr.t = t_g;
+    int64_t n = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        if (n_g[g] < 1 || t_g[g] < 1) return fail(h, ASR_ERR_ARG, "every group needs n >= 1 utterances of t >= 1 frames");
+        n += n_g[g];
+        gr.rows += (size_t)n_g[g] * t_g[g];
+        gr.t_max = std::max(gr.t_max, (int)t_g[g]);
+    }
+    if (n > (1 << 20) || gr.rows > ((size_t)1 << 31) - 64) return fail(h, ASR_ERR_ARG, "too many utterances or frames in one call");
+    if ((rc = check_xshape(h, (int)n, gr.t_max, d))) return rc;
+    if ((rc = ensure_encoder_rows(h, (int)n, gr.rows))) return rc;
+    std::vector<int32_t> ut(n), uoff(n), ulim(n);
+    {
+        size_t row0 = 0, u = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            for (int i = 0; i < n_g[g]; ++i, ++u) {
+                ut[u] = t_g[g];
+                uoff[u] = (int32_t)(row0 + (size_t)i * t_g[g]);
+                ulim[u] = std::min(t_g[g] + 50, (int)h->cfg.max_target_length);                 // model.py:310 with the group's T
+            }
+            row0 += (size_t)n_g[g] * t_g[g];
+        }
+    }
+    TmpBufs tb;
+    int32_t *dt, *doff, *dlim;
+    HIP_TRY(h, tb.up(&dt, ut.data(), (size_t)n, h->stream));
+    HIP_TRY(h, tb.up(&doff, uoff.data(), (size_t)n, h->stream));
+    HIP_TRY(h, tb.up(&dlim, ulim.data(), (size_t)n, h->stream));
+    gr.d_t = dt; gr.d_off = doff; gr.d_limit = dlim;
+    HIP_TRY(h, hipMemcpyAsync(h->xin, X, gr.rows * (size_t)d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = decode_core(h, h->xin, (int)n, gr.t_max, Y, y_capacity, len_out, nullptr, &gr);
+    hipError_t e = hipStreamSynchronize(h->stream);               // the per-call arrays are freed on return
+    if (!rc && e != hipSuccess) return fail(h, ASR_ERR_HIP, hipGetErrorString(e));
+    return rc;
+}
+
+int asr_decode_groups(asr_handle* h, const float* X, int32_t n_groups, const int32_t* n_g, const int32_t* t_g, int32_t d, int32_t* Y,
+                      int64_t y_capacity, int32_t* len_out)
+{
+    if (!h) return ASR_ERR_ARG;
+    return with_range_retry(h, [&]() { return asr_decode_groups_once(h, X, n_groups, n_g, t_g, d, Y, y_capacity, len_out); });
 }
 
 // Replaces Evaluator.loss (evaluate.py:49-50): sess.run(model.loss_sum) for one tower = encoder, teacher-forced

@@ -651,6 +651,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
     __shared__ BeamLds L;
     const int u = blockIdx.x, tid = threadIdx.x;
     const int pos = *st.pos, cur = pos & 1, nxt = cur ^ 1;
+    // joint decode of groups: this utterance's own loop (model.py:305-312 with ITS T) ends after limit_u + 1 steps
+    const bool stopped = st.limit_u && pos + 1 > st.limit_u[u];
     beam_prune_block(st.scores[cur], st.finished[cur], cand_scores, cand_tokens, k, u, L);
     // preds = concat(gather(preds, parent), token); ancestry table gathered the same way (model.py:296-298)
     const int w = st.width;
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
     if (tid < k) {
         const int r = u * k + tid;
         st.scores[nxt][r] = L.nscore[tid];
-        st.finished[nxt][r] = (L.ntok[tid] == 3) ? 1 : 0;                 // :301
+        st.finished[nxt][r] = (L.ntok[tid] == 3 || stopped) ? 1 : 0;      // :301
         st.preds[nxt][(size_t)r * w + pos + 1] = L.ntok[tid];
         st.tokens[r] = L.ntok[tid];
         st.parents[r] = u * k + L.npar[tid];
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
     if (tid == 0) {
         int any = 0;
         for (int i = 0; i < k; ++i) any |= (L.ntok[i] != 3);
-        if (any) atomicAdd(st.unfinished, 1);
+        if (any && !stopped) atomicAdd(st.unfinished, 1);
         __threadfence();                                      // the count before the ticket
         int32_t* arrive = st.pos + 3;
         if (atomicAdd(arrive, 1) == (int)gridDim.x - 1) {

@@ -92,8 +92,26 @@ def gather_hypotheses(local_ids, local_hyps, n_total, width, group=None, device=
     return out
 
 
+def merge_jobs(batch_ids, sizes, tmax, merge_utts):
+    """Jobs for joint decodes (`Engine.decode_groups`): the batches of `batch_ids` in order of padded length, joined while
+    a job stays within `merge_utts` utterances (neighbours in length share most of their loop: similar limits, similar
+    key counts).  Returns a list of lists of batch ids; merge_utts <= 0: one batch per job."""
+    if merge_utts <= 0:
+        return [[b] for b in batch_ids]
+    jobs, cur, n = [], [], 0
+    for b in sorted(batch_ids, key=lambda b: (tmax[b], b)):
+        if cur and n + sizes[b] > merge_utts:
+            jobs.append(cur)
+            cur, n = [], 0
+        cur.append(b)
+        n += sizes[b]
+    if cur:
+        jobs.append(cur)
+    return jobs
+
+
 def decode_sharded(decode_fn, feats, tokens_per_batch, beam, max_target_length, rank=0, world_size=1,
-                   group=None, device=None):
+                   group=None, device=None, merge_utts=0):
     """Bucket `feats` (list of [T_u, D] arrays) by length, deal the batches over ranks, decode this
     rank's batches with `decode_fn(X) -> Y`, gather.  Returns int32 [len(feats), max_target_length+1].
 
@@ -101,11 +119,16 @@ def decode_sharded(decode_fn, feats, tokens_per_batch, beam, max_target_length, 
     weight replica, K/V cache and streams): the rank's batches are then decoded by that many host threads
     side by side, most expensive first.  Bucketed batches are small (ten-odd utterances) and a small batch is
     bound by kernel latency, not by the GPU, so two or three of them share the GPU almost for free; the
-    hypotheses do not depend on it (utterances are independent, every batch is decoded exactly as alone)."""
+    hypotheses do not depend on it (utterances are independent, every batch is decoded exactly as alone).
+
+    merge_utts > 0: the rank's batches are joined into joint decodes of up to that many utterances (`merge_jobs`) and
+    `decode_fn` is called with a LIST of padded batches and returns the list of their Y (`Engine.decode_groups`: every batch
+    keeps its own padded length everywhere it enters the arithmetic; one beam search over all of them)."""
     fns = list(decode_fn) if isinstance(decode_fn, (list, tuple)) else [decode_fn]
     lengths = [len(f) for f in feats]
     batches = bucket_batches(lengths, tokens_per_batch)
-    costs = [batch_cost(len(b), max(lengths[i] for i in b), beam, max_target_length) for b in batches]
+    tmaxes = [max(lengths[i] for i in b) for b in batches]
+    costs = [batch_cost(len(b), tmaxes[bi], beam, max_target_length) for bi, b in enumerate(batches)]
     mine = assign_batches(costs, world_size)[rank]
 
     def make(bi):
@@ -117,25 +140,37 @@ def decode_sharded(decode_fn, feats, tokens_per_batch, beam, max_target_length, 
         return X
 
     results = {}
-    if len(fns) == 1 or len(mine) < 2:
-        for bi in mine:
-            results[bi] = fns[0](make(bi))
+    jobs = merge_jobs(mine, [len(b) for b in batches], tmaxes, merge_utts)
+
+    def run(fn, job):
+        if merge_utts > 0:
+            Ys = fn([make(bi) for bi in job])
+            if len(Ys) != len(job):
+                raise RuntimeError('decode_fn returned %d results for %d batches' % (len(Ys), len(job)))
+            for bi, Y in zip(job, Ys):
+                results[bi] = Y
+        else:
+            results[job[0]] = fn(make(job[0]))
+
+    if len(fns) == 1 or len(jobs) < 2:
+        for job in jobs:
+            run(fns[0], job)
     else:
         import queue
         import threading
         todo = queue.Queue()
-        for bi in sorted(mine, key=lambda b: -costs[b]):
-            todo.put(bi)
+        for job in sorted(jobs, key=lambda j: -sum(costs[b] for b in j)):
+            todo.put(job)
         errors = []
 
         def worker(fn):
             while not errors:
                 try:
-                    bi = todo.get_nowait()
+                    job = todo.get_nowait()
                 except queue.Empty:
                     return
                 try:
-                    results[bi] = fn(make(bi))
+                    run(fn, job)
                 except Exception as ex:          # re-raised on the calling thread
                     errors.append(ex)
         threads = [threading.Thread(target=worker, args=(fn,)) for fn in fns]

@@ -117,6 +117,32 @@ class Engine(object):
         _lib.check(self._h, lib.asr_decode(self._h, _lib.fptr(X), n, t, d, _lib.iptr(Y), Y.size, C.byref(ln)))
         return np.ascontiguousarray(Y.reshape(-1)[:n * ln.value].reshape(n, ln.value))
 
+    def decode_groups(self, Xs):
+        """Several batches, each float32 [n_g, t_g, input_dim] padded to its OWN t_g (the bucketed reader's batches), decoded
+        as one beam search (`asr_decode_groups`: every batch through the encoder with its own T, the decode steps over all
+        utterances together) -> list of int32 [n_g, len], padded with 3; an utterance's hypothesis up to its first 3 is
+        what `decode` of its own batch gives (up to float32 summation order)."""
+        Xs = [_lib.f32(X) for X in Xs if X.shape[0] > 0]
+        if not Xs:
+            return []
+        d = Xs[0].shape[2]
+        if any(X.ndim != 3 or X.shape[2] != d for X in Xs):
+            raise ValueError('every batch must be [n, t, input_dim]')
+        ng = np.array([X.shape[0] for X in Xs], np.int32)
+        tg = np.array([X.shape[1] for X in Xs], np.int32)
+        flat = np.concatenate([X.reshape(-1) for X in Xs])
+        n = int(ng.sum())
+        Y = np.empty((n, self.max_len), np.int32)
+        ln = C.c_int32(0)
+        _lib.check(self._h, lib.asr_decode_groups(self._h, _lib.fptr(flat), len(Xs), _lib.iptr(ng), _lib.iptr(tg), d, _lib.iptr(Y), Y.size,
+                                                  C.byref(ln)))
+        Y = Y.reshape(-1)[:n * ln.value].reshape(n, ln.value)
+        out, r = [], 0
+        for k in ng:
+            out.append(np.ascontiguousarray(Y[r:r + k]))
+            r += int(k)
+        return out
+
     def loss(self, X, Y):
         """== sess.run(model.loss_sum) for one tower: X float32 [n, t, d], Y int32 [n, ty] (0 = padding) -> float."""
         X = _lib.f32(X)
@@ -409,6 +435,33 @@ class Model(object):
     def predict_batches(self, batches):
         """predict(X) for every X of `batches`, in order.  One tower on one GPU with `test.engines_per_gpu` >= 2: that many
         batches are in flight at a time (EnginePool); otherwise one after the other, like evaluate.py:52-66."""
+        merge = int((self._config.test.merge_utts if self._config.test else None) or os.environ.get('ASR_AMD_MERGE_UTTS') or 0)
+        if merge > 0 and self._num_towers == 1:
+            # build extension (not a reference key) `test.merge_utts`: consecutive batches of the bucketed reader are joined
+            # into joint decodes of up to that many utterances (Engine.decode_groups: every batch keeps its own padded length
+            # wherever it enters the arithmetic, the decode steps run over all of them), results handed back batch by batch
+            def jobs():
+                cur, n = [], 0
+                for X in batches:
+                    X = np.asarray(X, dtype=np.float32)
+                    if cur and (n + X.shape[0] > merge or X.shape[0] == 0):
+                        yield cur
+                        cur, n = [], 0
+                    cur.append(X)
+                    n += X.shape[0]
+                    if X.shape[0] == 0:
+                        yield cur
+                        cur, n = [], 0
+                if cur:
+                    yield cur
+
+            def call(e, Xs):
+                return [e.decode(Xs[0])] if len(Xs) == 1 else e.decode_groups(Xs)
+            if len(self.pools) == 1 and len(self.pools[0].engines) > 1:
+                done = self.pools[0].map(call, jobs())
+            else:
+                done = (call(self.engines[0], Xs) for Xs in jobs())
+            return (Y for Ys in done for Y in Ys)
         if self._num_towers == 1 and len(self.pools) == 1 and len(self.pools[0].engines) > 1:
             return self.pools[0].map(lambda e, X: e.decode(np.asarray(X, dtype=np.float32)), batches)
         return (self.predict(X) for X in batches)

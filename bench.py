@@ -245,7 +245,7 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
     def make_decode_fn(e):
         def decode_fn(X):
             t0 = time.perf_counter()
-            Y = e.decode(X)
+            Y = e.decode_groups(X) if args.merge_utts > 0 else e.decode(X)
             with busy_lock:
                 busy[0] += time.perf_counter() - t0
             return Y
@@ -256,7 +256,7 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
 
     def step():
         return D.decode_sharded(decode_fns, feats, args.tokens_per_batch, args.beam, args.max_target_length, rank=rank,
-                                world_size=world, device=device)
+                                world_size=world, device=device, merge_utts=args.merge_utts)
 
     def fence():
         torch.cuda.synchronize()
@@ -296,6 +296,10 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
                                    % (args.utts_per_gpu, sum(raw_lens) / 100.0, args.tokens_per_batch, len(batches), world, len(engines), args.vocab,
                                       args.beam, args.max_target_length),
                        'parallelism': 'dp%d' % world, 'precision': args.precision, 'batches': len(batches), 'engines_per_gpu': len(engines),
+                       # > 0: a rank's batches joined into joint decodes of up to that many utterances (Engine.decode_groups)
+                       'merge_utts': args.merge_utts,
+                       'joint_decodes': [len(D.merge_jobs(o, [len(b) for b in batches], [max(lengths[i] for i in b) for b in batches],
+                                                         args.merge_utts)) for o in owners],
                        'batch_sizes': sorted(len(b) for b in batches)[::max(1, len(batches) // 16)],
                        'range_retries': eng.range_retries()},
             # per-rank seconds inside Engine.decode over the timed steps (summed over the rank's engine threads), and how even the deal was
@@ -330,6 +334,8 @@ def main():
                     'engine handle of its own (asr_amd.model.EnginePool); 1 = one step at a time')
     ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_f16x3'), choices=sorted(PRECISION_INFO))
     ap.add_argument('--workload', default='fixed', choices=['fixed', 'bucketed'])
+    ap.add_argument('--merge-utts', type=int, default=0, help='--workload bucketed: join a rank\'s batches into joint decodes of up to this '
+                    'many utterances (Engine.decode_groups); 0 = batch by batch like the reference\'s translate loop')
     ap.add_argument('--utts-per-gpu', type=int, default=512, help='--workload bucketed: utterances per GPU (a test set of a few hundred utterances fills the 10-frame buckets; 64 leaves mostly single-utterance batches)')
     ap.add_argument('--engines-per-gpu', type=int, default=4, help='--workload bucketed: engine handles (weight replica, K/V cache, '
                     'streams, one host thread each) that decode the rank\'s batches side by side')

@@ -112,6 +112,18 @@ int asr_finalize_weights(asr_handle* h);
 int asr_decode(asr_handle* h, const float* X, int32_t n, int32_t t, int32_t d,
                int32_t* Y, int64_t y_capacity, int32_t* len_out);
 
+/* Several batches of the reference's bucketed reader (utils.py:285-323), each padded to its OWN T, decoded as ONE beam
+ * search.  No counterpart in the reference, whose translate loop (evaluate.py:52-66) runs one sess.run per batch: ten-frame
+ * buckets of a few utterances leave every decode position streaming all weights for a handful of rows.  X = group after
+ * group, group g being [n_g[g], t_g[g], d] row-major; Y [sum n_g, *len_out] in the same order.  Each group goes through the
+ * encoder with its own T (the input layer norm runs over (T, H), model.py:453) and its utterances attend over their own T
+ * keys; the decode steps run over all utterances' beams together.  An utterance's own loop limit min(T + 50,
+ * max_target_length) (model.py:310) is kept: once it is reached its beams keep their scores and are padded with 3, which is
+ * what the reference's loop does to finished beams (model.py:238-253), so hypotheses read up to the first 3 - what
+ * indices_to_words does (utils.py) - equal those of group-by-group asr_decode calls up to float32 summation order (K-slice
+ * counts follow the row count); the trailing columns of Y differ: *len_out is the joint loop's length. */
+int asr_decode_groups(asr_handle* h, const float* X, int32_t n_groups, const int32_t* n_g, const int32_t* t_g, int32_t d,
+                      int32_t* Y, int64_t y_capacity, int32_t* len_out);
 /* Same, with X already resident in this device's memory (what bench.py times).  If
  * raw_frames > 0, X_dev is instead RAW fbank [n, raw_frames, raw_dim] and the frame-stacking
  * front end (left, right, sub) runs on the device first (third_party/feat_convert/io/fea.py:142-149),

@@ -100,3 +100,37 @@ def test_decode_sharded_with_several_decode_fns_gives_the_same_rows_and_propagat
         raise RuntimeError('decode failed')
     with pytest.raises(RuntimeError, match='decode failed'):
         D.decode_sharded([boom, boom], feats, 300, 2, 6)
+
+
+def test_merge_jobs_and_merged_decode_sharded():
+    """dist.merge_jobs joins a rank's batches, in order of padded length, into jobs of at most `merge_utts` utterances (a batch
+    larger than that stays a job of its own); decode_sharded then hands decode_fn LISTS of padded batches and takes back the
+    list of their Y - same gathered hypotheses as batch by batch."""
+    from asr_amd import dist as D
+    sizes = [3, 1, 9, 2, 2, 4]
+    tmax = [50, 20, 30, 20, 90, 31]
+    assert D.merge_jobs([0, 1, 2, 3, 4, 5], sizes, tmax, 0) == [[0], [1], [2], [3], [4], [5]]
+    jobs = D.merge_jobs([0, 1, 2, 3, 4, 5], sizes, tmax, 6)
+    assert jobs == [[1, 3], [2], [5], [0, 4]]                       # by length: 1, 3 (20) | 2 (30, nine utterances alone) | 5 (31) | 0, 4
+    assert sorted(sum(jobs, [])) == [0, 1, 2, 3, 4, 5]
+    assert D.merge_jobs([4, 0], sizes, tmax, 100) == [[0, 4]]
+
+    rng = np.random.default_rng(3)
+    lens = [int(x) for x in rng.integers(50, 140, size=23)]
+    feats = [np.full((ln, 4), float(i + 1), np.float32) for i, ln in enumerate(lens)]
+    calls = []
+
+    def fake(X):                                                     # hypothesis = [utterance id, its padded length]
+        return np.stack([np.array([int(X[r, 0, 0]) - 1, X.shape[1]], np.int32) for r in range(X.shape[0])])
+
+    def fake_groups(Xs):
+        calls.append([X.shape[0] for X in Xs])
+        return [fake(X) for X in Xs]
+
+    want = D.decode_sharded(fake, feats, 300, 2, 7)
+    got = D.decode_sharded(fake_groups, feats, 300, 2, 7, merge_utts=6)
+    assert np.array_equal(got, want)
+    assert all(sum(c) <= 6 or len(c) == 1 for c in calls) and any(len(c) > 1 for c in calls)
+    assert np.array_equal(D.decode_sharded([fake_groups, fake_groups], feats, 300, 2, 7, merge_utts=6), want)
+    with pytest.raises(RuntimeError):
+        D.decode_sharded(lambda Xs: [], feats, 300, 2, 7, merge_utts=6)

@@ -152,10 +152,10 @@ def _write_vocab_bpe(path, n):
     return words
 
 
-@pytest.mark.parametrize('engines_per_gpu', [None, 2])
-def test_evaluator_end_to_end_from_checkpoint_dir_to_hypothesis_file(tmp_path, engines_per_gpu):
-    """(`engines_per_gpu` = the build's `test.engines_per_gpu` key: batches decoded two at a time by two engine handles -
-    the same file.)  evaluate.py:25-38,52-74: Evaluator().init_from_config(config) restores tf.train.latest_checkpoint(model_dir) (a
+@pytest.mark.parametrize('engines_per_gpu,merge_utts', [(None, None), (2, None), (None, 4), (2, 3)])
+def test_evaluator_end_to_end_from_checkpoint_dir_to_hypothesis_file(tmp_path, engines_per_gpu, merge_utts):
+    """(`engines_per_gpu` = the build's `test.engines_per_gpu` key: batches decoded two at a time by two engine handles;
+    `merge_utts` = the build's `test.merge_utts` key: consecutive batches joined into joint decodes - the same file.)  evaluate.py:25-38,52-74: Evaluator().init_from_config(config) restores tf.train.latest_checkpoint(model_dir) (a
     TF-V2 bundle with optimizer slots and global_step beside the graph variables), translate() batches the scp in
     order, decodes, writes `uttid<TAB>tokens` and strips the BPE markers.  Expected file = the oracle's hypotheses
     through the reference's indices_to_words + sed expression, byte for byte."""
@@ -199,6 +199,8 @@ def test_evaluator_end_to_end_from_checkpoint_dir_to_hypothesis_file(tmp_path, e
     }
     if engines_per_gpu:
         cfg_yaml['test']['engines_per_gpu'] = engines_per_gpu
+    if merge_utts:
+        cfg_yaml['test']['merge_utts'] = merge_utts
     cfg_path = str(tmp_path / 'config.yaml')
     with open(cfg_path, 'w') as f:
         yaml.safe_dump(cfg_yaml, f)
@@ -292,6 +294,13 @@ def test_decode_sharded_real_engine_matches_oracle_on_the_same_bucketed_batches(
                 fns = [e.decode for e in [eng] + more]
                 for _ in range(2):
                     assert np.array_equal(D.decode_sharded(fns, feats, tokens_per_batch, ocfg.beam_size, ocfg.max_target_length), want)
+                # ... and with the batches joined into joint decodes (Engine.decode_groups): the gather pads with 3, so even the
+                # rows of utterances that stop at their own loop limit come out the same
+                for merge in (4, 7, 100):
+                    assert np.array_equal(D.decode_sharded(eng.decode_groups, feats, tokens_per_batch, ocfg.beam_size,
+                                                           ocfg.max_target_length, merge_utts=merge), want)
+                assert np.array_equal(D.decode_sharded([e.decode_groups for e in [eng] + more], feats, tokens_per_batch, ocfg.beam_size,
+                                                       ocfg.max_target_length, merge_utts=5), want)
             finally:
                 for e in more:
                     e.close()
