@@ -566,6 +566,7 @@ int ensure_decoder_capacity(asr_handle* h, int n)
     rc |= dev_alloc_t(h, &h->part, (size_t)ASR_MAX_SPLITK * R * 3 * H);
     rc |= dev_alloc_t(h, &h->dhid, R * (size_t)h->F);
     h->logit_split = std::min(2, gemm_pick_split_k((int)R, h->V, (int)H, gemm_nprod(h, (int)H)));        // <= 2 slabs of logits
+    if (const char* e = getenv("ASR_AMD_LOGIT_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2) h->logit_split = v; }   // development
     rc |= dev_alloc_t(h, &h->logits, 2 * R * (size_t)h->V);
     rc |= dev_alloc_t(h, &h->cand_scores, R * (size_t)h->K);
     rc |= dev_alloc_t(h, &h->cand_tokens, R * (size_t)h->K);
