@@ -233,6 +233,40 @@ def test_evaluator_end_to_end_from_checkpoint_dir_to_hypothesis_file(tmp_path, e
     assert not os.path.exists(out_path + '.tmp')
 
 
+def test_joint_decode_full_size_is_bit_identical_to_batch_by_batch_with_pinned_k_slices(monkeypatch):
+    """asr_decode_groups at the size it is for: the char architecture, beam 10, three bucketed batches of 30 / 24 / 21
+    utterances with different padded lengths (750 beam rows: whole-batch tiles, the HIP-graph replay of the decode steps).
+    K-slice counts follow the row count, and with them the order of the float32 sums; pinned to one slice everywhere
+    (ASR_AMD_SPLITS / ASR_AMD_LOGIT_SPLIT, development switches) every sum is taken in the same order whatever the batch
+    composition, so the joint decode must reproduce the batch-by-batch hypotheses BIT for bit - any difference would be a
+    defect of the per-batch bookkeeping (own T in the encoder, key offsets, own loop limit: T = 17 gives limit 60 < 66)."""
+    monkeypatch.setenv('ASR_AMD_SPLITS', '1,1,1')
+    monkeypatch.setenv('ASR_AMD_LOGIT_SPLIT', '1')
+    ocfg = O.make_config(beam_size=10, max_target_length=66)
+    W = O.random_weights(ocfg, seed=9, bias_scale=0.1, emb_scale=3.0)
+    rng = np.random.default_rng(404)
+    shapes = [(30, 300), (24, 50), (21, 204)]                        # (utterances, raw frames of the longest)
+    Xs = []
+    for i, (n, top) in enumerate(shapes):
+        lens = [top] + [int(x) for x in rng.integers(top - 9, top + 1, size=n - 1)]
+        Xs.append(O.make_batch(O.synthetic_fbank(n, lens, seed=500 + i)))
+    assert [X.shape[1] for X in Xs] == [100, 17, 68]
+    eng = _engine(ocfg, W)
+    try:
+        joint = eng.decode_groups(Xs)
+        steps = joint[0].shape[1]
+        assert all(Y.shape[1] == steps for Y in joint) and steps <= 67
+        for X, Yj in zip(Xs, joint):
+            Ya = eng.decode(X)
+            own = Ya.shape[1]
+            assert own <= min(X.shape[1] + 50, 66) + 1
+            assert np.array_equal(Yj[:, :own], Ya)
+            assert np.all(Yj[:, own:] == 3)
+        assert np.array_equal(np.concatenate(eng.decode_groups(Xs)), np.concatenate(joint))      # deterministic
+    finally:
+        eng.close()
+
+
 # ---- (d) bucketed + sharded path with the real engine ------------------------------------------------------------
 @pytest.mark.parametrize('world', [1, 2, 3])
 def test_decode_sharded_real_engine_matches_oracle_on_the_same_bucketed_batches(world):
