@@ -334,6 +334,7 @@ def main():
                     'engine handle of its own (asr_amd.model.EnginePool); 1 = one step at a time')
     ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_f16x3'), choices=sorted(PRECISION_INFO))
     ap.add_argument('--workload', default='fixed', choices=['fixed', 'bucketed'])
+    ap.add_argument('--no-two-steps', action='store_true', help='skip the two-steps-per-decode leg (--no-one-at-a-time skips it as well)')
     ap.add_argument('--merge-utts', type=int, default=0, help='--workload bucketed: join a rank\'s batches into joint decodes of up to this '
                     'many utterances (Engine.decode_groups); 0 = batch by batch like the reference\'s translate loop')
     ap.add_argument('--utts-per-gpu', type=int, default=512, help='--workload bucketed: utterances per GPU (a test set of a few hundred utterances fills the 10-frame buckets; 64 leaves mostly single-utterance batches)')
@@ -524,6 +525,33 @@ def main():
                                          'ms_per_step': 1000.0 * dt / max(args.alt_steps, 1), 'steps': args.alt_steps,
                                          'utterances_identical': '%d of %d' % (int(same.sum()), n)}
             p1.close()
+        if world == 1 and nfl > 1 and not (args.no_two_steps or args.no_one_at_a_time):
+            # two steps per decode call: every handle decodes TWO 64-utterance batches as one run of kernels (what
+            # Engine.decode_groups does with the bucketed reader's batches; here both have the same padded length, so the call
+            # is a 128-utterance decode).  Reported beside the headline, never as `value`.
+            p2 = EnginePool(cfg, local_rank, nfl)
+            p2.load_weights(W)
+            raw2 = np.concatenate([raw, synthetic_raw(n, t_raw, seed=2000 + rank)])
+            d_raw2 = torch.from_numpy(raw2).cuda(local_rank)
+
+            def decode2(e, _=None):
+                return e.decode_dev(d_raw2.data_ptr(), 2 * n, 0, 0, raw=front)
+            for _ in p2.map(decode2, range(nfl)):
+                pass
+            k2 = max(nfl, args.alt_steps // 2)
+            fence()
+            t0 = time.perf_counter()
+            for Y2 in p2.map(decode2, range(k2)):
+                pass
+            fence()
+            dt = time.perf_counter() - t0
+            m = min(Y2.shape[1], Y.shape[1])
+            same = np.all(Y2[:n, :m] == Y[:, :m], axis=1)
+            out['two_steps_per_decode'] = {'value': 2 * n * t_raw / 100.0 * k2 / dt, 'unit': 'audio-sec/sec',
+                                           'ms_per_step': 1000.0 * dt / (2 * k2), 'steps': 2 * k2, 'decodes_in_flight': nfl,
+                                           'utterances_identical': '%d of %d' % (int(same.sum()), n)}
+            p2.close()
+            del d_raw2
         if world == 1 and not args.no_alt_precisions:
             # the other dense-layer arithmetics on the same batch, timed by this same run the same way (fresh handles;
             # the headline's are closed first)
