@@ -407,6 +407,7 @@ def _upto_eos(row):
     (3, 25, [(60, 62), (90,), (75, 75, 74)]),            # every group stops by its own EOS or the common limit
     (4, 60, [(15,), (100, 95), (30, 31)]),               # T + 50 < max_target_length for the short groups: their own limits bind
     (1, 30, [(40,), (41,), (80,)]),                      # greedy, one-utterance groups (config 1's shape)
+    (1, 61, [(15,), (100,), (16, 14)]),                  # greedy: hypotheses that are still unfinished at their own limit
 ])
 def test_joint_decode_of_groups_gives_each_group_its_own_hypotheses(beam, mtl, lens_groups):
     """asr_decode_groups: batches padded to different T decoded as ONE beam search.  Each group keeps its own T everywhere T
@@ -430,6 +431,16 @@ def test_joint_decode_of_groups_gives_each_group_its_own_hypotheses(beam, mtl, l
                 assert _upto_eos(Yg[u]) == _upto_eos(want[u]), (X.shape, u)
                 assert _upto_eos(Yg[u]) == _upto_eos(alone[u])
                 assert len(_upto_eos(want[u])) <= min(X.shape[1] + 50, mtl) + 1
+        if mtl == 60:
+            # the case must exercise the per-utterance limit: the first group (T = 5) stops after min(5 + 50, 60) + 1 = 56 steps
+            # with unfinished beams while the joint loop goes on for the others
+            alone0 = eng.decode(Xs[0])
+            assert alone0.shape[1] == 56 and got[0].shape[1] > 56
+            assert np.array_equal(got[0][:, :56], alone0) and np.all(got[0][:, 56:] == 3)
+        if mtl == 61:
+            alone0 = eng.decode(Xs[0])                                 # T = 5: 56 tokens and no </S> among them
+            assert alone0.shape[1] == 56 and 3 not in alone0[0] and got[0].shape[1] > 56
+            assert np.array_equal(got[0][:, :56], alone0) and np.all(got[0][:, 56:] == 3)
         # a single group is the plain decode
         one = eng.decode_groups([Xs[1]])[0]
         assert np.array_equal(one, eng.decode(Xs[1]))
