@@ -241,3 +241,37 @@ def test_engine_pool_map_keeps_order_bounds_what_is_in_flight_and_propagates_err
     # one handle: plain sequential calls on the caller's thread
     pool.engines = [Fake(0)]
     assert list(pool.map(lambda e, it: (threading.get_ident(), it), range(3))) == [(threading.get_ident(), i) for i in range(3)]
+
+
+def test_predict_batches_merge_utts_groups_consecutive_batches_and_keeps_their_order():
+    """`test.merge_utts` (build extension): Model.predict_batches joins CONSECUTIVE batches into joint decodes of at most that
+    many utterances, hands the results back batch by batch in order, decodes a lone batch (and an empty one) with the plain
+    call, and leaves everything alone when the key is absent.  Stand-in handle, no GPU."""
+    from asr_amd.model import Model
+    calls = []
+
+    class Fake(object):
+        def decode(self, X):
+            calls.append(('one', X.shape[0]))
+            return np.full((X.shape[0], 2), X.shape[1], np.int32) if X.shape[0] else np.zeros((0, 0), np.int32)
+
+        def decode_groups(self, Xs):
+            calls.append(('joint', [X.shape[0] for X in Xs]))
+            return [np.full((X.shape[0], 2), X.shape[1], np.int32) for X in Xs]
+
+    def batches():
+        for n, t in [(2, 10), (2, 11), (1, 12), (0, 5), (3, 13), (3, 14), (5, 15)]:
+            yield np.zeros((n, t, 4), np.float32)
+
+    cfg = product_config(tiny_config())
+    cfg.test['merge_utts'] = 4
+    m = Model(cfg, 1, devices=[0])
+    m.engines = [Fake()]
+    out = list(m.predict_batches(batches()))
+    assert [y.shape[0] for y in out] == [2, 2, 1, 0, 3, 3, 5]
+    assert [int(y[0, 0]) for y in out if y.shape[0]] == [10, 11, 12, 13, 14, 15]
+    assert calls == [('joint', [2, 2]), ('one', 1), ('one', 0), ('one', 3), ('one', 3), ('one', 5)]
+    calls[:] = []
+    cfg.test['merge_utts'] = None
+    m.predict = lambda X: ('plain', X.shape[0])
+    assert [r for r in m.predict_batches(batches())][:2] == [('plain', 2), ('plain', 2)] and calls == []
