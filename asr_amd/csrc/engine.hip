@@ -71,6 +71,8 @@ struct asr_handle {
     const int32_t* grp_t = nullptr;
     const int32_t* grp_off = nullptr;
     double grp_rows = 0.0;
+    int32_t* grp_buf = nullptr;         // device home of those arrays and of the per-utterance loop limits: [3][grp_cap]
+    size_t grp_cap = 0;
     int logit_split = 1;                // K slices of the logits GEMM (their slabs are summed by the top-k kernel)
     float* emb_gemm = nullptr;          // logits operand when tied: = emb (f32 mode) or its bf16 planes
     hipStream_t stream = nullptr;
@@ -1477,17 +1479,21 @@ static int asr_decode_groups_once(asr_handle* h, const float* X, int32_t n_group
             row0 += (size_t)n_g[g] * t_g[g];
         }
     }
-    TmpBufs tb;
-    int32_t *dt, *doff, *dlim;
-    HIP_TRY(h, tb.up(&dt, ut.data(), (size_t)n, h->stream));
-    HIP_TRY(h, tb.up(&doff, uoff.data(), (size_t)n, h->stream));
-    HIP_TRY(h, tb.up(&dlim, ulim.data(), (size_t)n, h->stream));
+    if ((size_t)n > h->grp_cap) {                                  // kept by the handle: no allocation per call (a free would wait
+        dev_free(h, h->grp_buf);                                   // for the other handles' kernels too)
+        h->grp_buf = nullptr; h->grp_cap = 0;
+        const size_t cap = std::max<size_t>((size_t)n, 256);
+        if (dev_alloc_t(h, &h->grp_buf, 3 * cap)) return ASR_ERR_HIP;
+        h->grp_cap = cap;
+    }
+    int32_t *dt = h->grp_buf, *doff = h->grp_buf + h->grp_cap, *dlim = h->grp_buf + 2 * h->grp_cap;
+    // (the host vectors outlive the copies: decode_core has waited for the stream when it returns)
+    HIP_TRY(h, hipMemcpyAsync(dt, ut.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(doff, uoff.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dlim, ulim.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     gr.d_t = dt; gr.d_off = doff; gr.d_limit = dlim;
     HIP_TRY(h, hipMemcpyAsync(h->xin, X, gr.rows * (size_t)d * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    rc = decode_core(h, h->xin, (int)n, gr.t_max, Y, y_capacity, len_out, nullptr, &gr);
-    hipError_t e = hipStreamSynchronize(h->stream);               // the per-call arrays are freed on return
-    if (!rc && e != hipSuccess) return fail(h, ASR_ERR_HIP, hipGetErrorString(e));
-    return rc;
+    return decode_core(h, h->xin, (int)n, gr.t_max, Y, y_capacity, len_out, nullptr, &gr);
 }
 
 int asr_decode_groups(asr_handle* h, const float* X, int32_t n_groups, const int32_t* n_g, const int32_t* t_g, int32_t d, int32_t* Y,
