@@ -447,3 +447,39 @@ def test_joint_decode_of_groups_gives_each_group_its_own_hypotheses(beam, mtl, l
         assert np.array_equal(eng.decode(Xs[0]), O.build_test_model(Xs[0], W, ocfg, num_gpus=1))      # the handle is as before
     finally:
         eng.close()
+
+
+def test_joint_decode_rejects_bad_group_descriptions_and_leaves_the_handle_usable():
+    """asr_decode_groups through the C ABI: a group without utterances or frames, no groups, a null pointer, a wrong feature
+    width and an output buffer that is too small are refused with an error code and a message; the handle still decodes."""
+    import ctypes as C
+    from asr_amd import _lib as L
+    from asr_amd.model import Engine
+    ocfg = tiny_config(beam_size=2, max_target_length=6)
+    W = O.random_weights(ocfg, seed=2, bias_scale=0.1)
+    eng = Engine(product_config(ocfg), 0)
+    eng.load_weights(W)
+    try:
+        Xa, Xb = tiny_inputs((30, 33), seed=1), tiny_inputs((60,), seed=2)
+        flat = np.concatenate([Xa.reshape(-1), Xb.reshape(-1)])
+        Y = np.empty((3, 16), np.int32)
+        ln = C.c_int32(0)
+
+        def call(ng, tg, d=320, x=flat, cap=Y.size, groups=None):
+            ng, tg = np.array(ng, np.int32), np.array(tg, np.int32)
+            return L.lib.asr_decode_groups(eng._h, L.fptr(x) if x is not None else None, len(ng) if groups is None else groups,
+                                           L.iptr(ng), L.iptr(tg), d, L.iptr(Y), cap, C.byref(ln))
+        good = ([2, 1], [Xa.shape[1], Xb.shape[1]])
+        assert call(*good) == 0 and 1 <= ln.value <= 7
+        want = Y.reshape(-1)[:3 * ln.value].reshape(3, ln.value).copy()
+        assert call([2, 0], good[1]) != 0 and b'group' in L.lib.asr_last_error(eng._h)
+        assert call([2, 1], [Xa.shape[1], 0]) != 0
+        assert call(*good, groups=0) != 0
+        assert call(*good, x=None) != 0
+        assert call(*good, d=319) != 0
+        assert call(*good, cap=2) != 0 and b'Y too small' in L.lib.asr_last_error(eng._h)
+        assert call(*good) == 0
+        assert np.array_equal(Y.reshape(-1)[:3 * ln.value].reshape(3, ln.value), want)
+        assert np.array_equal(eng.decode(Xb), O.build_test_model(Xb, W, ocfg, num_gpus=1))
+    finally:
+        eng.close()
