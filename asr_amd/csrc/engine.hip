@@ -597,10 +597,24 @@ int ensure_decoder_capacity(asr_handle* h, int n)
 
 // ---- encoder (model.py:444-490) ----------------------------------------------------------------
 // X_dev [n, t, D] -> h->x0 [n*t, H] (encoder output), h->pad / h->pad2 [n*t]
-int run_encoder(asr_handle* h, const float* X_dev, int n, int t, int32_t* pad2_dst = nullptr)
+// Groups of utterances padded to different T, decoded as ONE beam search (asr_decode_groups): X_dev holds group after group.
+struct Groups {
+    int count = 0;
+    const int32_t* n = nullptr;        // host [count]
+    const int32_t* t = nullptr;        // host [count]
+    const int32_t *d_t = nullptr, *d_off = nullptr, *d_limit = nullptr;     // device [sum n]: per utterance
+    int t_max = 0;
+    size_t rows = 0;                   // sum n[g] * t[g]
+};
+
+// With `gr`: the rows of all groups go through the row-wise kernels (GEMMs, residual + layer norm, padding flags) together;
+// what depends on a group's own T - the input layer norm over (T, H) (model.py:453), the attention over its own keys - is
+// launched group by group on that group's rows.  (n, t) are then unused.
+int run_encoder(asr_handle* h, const float* X_dev, int n, int t, const Groups* gr = nullptr)
 {
-    if (!pad2_dst) pad2_dst = h->pad2;
-    const int M = n * t, H = h->H, F = h->F;
+    const int M = gr ? (int)gr->rows : n * t, H = h->H, F = h->F;
+    int32_t* pad2_dst = h->pad2;
+    if (gr) t = gr->t_max;
     int rc = ensure_pe(h, std::max(t, h->cfg.max_target_length + 2));
     if (rc) return rc;
     hipStream_t s = h->stream;
@@ -612,7 +626,16 @@ int run_encoder(asr_handle* h, const float* X_dev, int n, int t, int32_t* pad2_d
     if (rc) return rc;
     {
         ProfScope ps(h, "input_norm_timing", 0, 4.0 * M * H * 4.0);
-        HIP_TRY(h, launch_input_norm_timing(h->x1, h->in_gamma, h->in_beta, h->pe, n, t, H, h->norm_scratch, h->x0, s));   // :453,456
+        if (gr) {
+            size_t row0 = 0;
+            for (int g = 0; g < gr->count; ++g) {
+                HIP_TRY(h, launch_input_norm_timing(h->x1 + row0 * H, h->in_gamma, h->in_beta, h->pe, gr->n[g], gr->t[g], H, h->norm_scratch,
+                                                    h->x0 + row0 * H, s));
+                row0 += (size_t)gr->n[g] * gr->t[g];
+            }
+        } else {
+            HIP_TRY(h, launch_input_norm_timing(h->x1, h->in_gamma, h->in_beta, h->pe, n, t, H, h->norm_scratch, h->x0, s));   // :453,456
+        }
     }
     for (int l = 0; l < h->L; ++l) {
         const EncBlock& b = h->enc[l];
@@ -620,8 +643,18 @@ int run_encoder(asr_handle* h, const float* X_dev, int n, int t, int32_t* pad2_d
         rc = gemm(h, h->x0, b.wqkv, b.bqkv, h->qkv, M, 3 * H, H, EPI_BIAS, 1);                      // utils.py:612
         if (rc) return rc;
         {
-            ProfScope ps(h, "encoder_attention", 4.0 * n * (double)t * t * H, 4.0 * M * 4.0 * H);
-            HIP_TRY(h, launch_encoder_attention(h->qkv, h->pad, n, t, h->heads, h->x1, s));         // utils.py:624-631
+            double tt = (double)n * t * t;
+            if (gr) { tt = 0.0; for (int g = 0; g < gr->count; ++g) tt += (double)gr->n[g] * gr->t[g] * gr->t[g]; }
+            ProfScope ps(h, "encoder_attention", 4.0 * tt * H, 4.0 * M * 4.0 * H);
+            if (gr) {
+                size_t row0 = 0;
+                for (int g = 0; g < gr->count; ++g) {
+                    HIP_TRY(h, launch_encoder_attention(h->qkv + row0 * 3 * H, h->pad + row0, gr->n[g], gr->t[g], h->heads, h->x1 + row0 * H, s));
+                    row0 += (size_t)gr->n[g] * gr->t[g];
+                }
+            } else {
+                HIP_TRY(h, launch_encoder_attention(h->qkv, h->pad, n, t, h->heads, h->x1, s));     // utils.py:624-631
+            }
         }
         rc = gemm(h, h->x1, b.wo, nullptr, h->x2, M, H, H, EPI_PARTIAL, 1);                         // utils.py:632
         if (rc) return rc;
@@ -643,17 +676,26 @@ int run_encoder(asr_handle* h, const float* X_dev, int n, int t, int32_t* pad2_d
 }
 
 // cross-attention K/V of every decoder block, once per utterance (instead of once per step per beam)
-int run_cross_kv(asr_handle* h, int n, int t, size_t row_off = 0)
+int run_cross_kv(asr_handle* h, int n, int t, const Groups* gr = nullptr)
 {
-    const int M = n * t, H = h->H;
-    const size_t boff = row_off * H * (h->kv_bf16 ? 2 : 4);           // bytes: this group's K / V start behind row_off rows
+    const int M = gr ? (int)gr->rows : n * t, H = h->H;
+    const size_t esz = h->kv_bf16 ? 2 : 4;
     for (int l = 0; l < h->L; ++l) {
         int rc = gemm(h, h->x0, h->dec[l].wkv, h->dec[l].bkv, h->qkv, M, 2 * H, H, EPI_BIAS, 1);   // utils.py:618
         if (rc) return rc;
         ProfScope ps(h, "pack_cross_kv", 0, 4.0 * M * 4.0 * H);
-        HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, h->heads, reinterpret_cast<char*>(h->cross_k[l]) + boff,
-                                        reinterpret_cast<char*>(h->cross_v[l]) + boff, h->kv_bf16 ? 1 : 0,
-                                        h->nprod_active == 13 ? h->range_flag : nullptr, h->stream));
+        int32_t* rf = h->nprod_active == 13 ? h->range_flag : nullptr;
+        if (gr) {                                                     // every group's [n][heads][t][64] behind the groups before it
+            size_t row0 = 0;
+            for (int g = 0; g < gr->count; ++g) {
+                HIP_TRY(h, launch_pack_cross_kv(h->qkv + row0 * 2 * H, gr->n[g], gr->t[g], h->heads,
+                                                reinterpret_cast<char*>(h->cross_k[l]) + row0 * H * esz,
+                                                reinterpret_cast<char*>(h->cross_v[l]) + row0 * H * esz, h->kv_bf16 ? 1 : 0, rf, h->stream));
+                row0 += (size_t)gr->n[g] * gr->t[g];
+            }
+        } else {
+            HIP_TRY(h, launch_pack_cross_kv(h->qkv, n, t, h->heads, h->cross_k[l], h->cross_v[l], h->kv_bf16 ? 1 : 0, rf, h->stream));
+        }
     }
     return ASR_OK;
 }
@@ -915,16 +957,6 @@ void finalize_host(const int32_t* preds, const float* scores, int n, int K, int 
 struct TraceOut { int steps = 0; float* logits = nullptr; float* scores = nullptr; int32_t* tokens = nullptr; int32_t* parents = nullptr; };
 
 // X_dev [n,t,D] on device (already stacked) -> Y host
-// Groups of utterances padded to different T, decoded as ONE beam search (asr_decode_groups): X_dev holds group after group.
-struct Groups {
-    int count = 0;
-    const int32_t* n = nullptr;        // host [count]
-    const int32_t* t = nullptr;        // host [count]
-    const int32_t *d_t = nullptr, *d_off = nullptr, *d_limit = nullptr;     // device [sum n]: per utterance
-    int t_max = 0;
-    size_t rows = 0;                   // sum n[g] * t[g]
-};
-
 int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int64_t y_capacity, int32_t* len_out,
                 const TraceOut* tr, const Groups* gr = nullptr)
 {
@@ -937,22 +969,11 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
     int rc = ensure_decoder_capacity(h, n);
     if (rc) return rc;
     for (int rep = launches_of(h, "encoder"); rep > 0; --rep) {     // (encoder + cross K/V of the batch: idempotent as a whole)
-        if (gr) {
-            // every group through the encoder with ITS T (the input layer norm runs over (T, H), model.py:453: T is part of
-            // the arithmetic), its cross K / V and padding flags laid out behind the groups before it
-            size_t row0 = 0;
-            for (int g = 0; g < gr->count; ++g) {
-                rc = run_encoder(h, X_dev + row0 * h->D, gr->n[g], gr->t[g], h->pad2 + row0);
-                if (rc) return rc;
-                rc = run_cross_kv(h, gr->n[g], gr->t[g], row0);
-                if (rc) return rc;
-                row0 += (size_t)gr->n[g] * gr->t[g];
-            }
-            continue;
-        }
-        rc = run_encoder(h, X_dev, n, t);
+        // with groups: every group keeps ITS T wherever T is part of the arithmetic, its cross K / V and padding flags are laid
+        // out behind the groups before it
+        rc = run_encoder(h, X_dev, n, t, gr);
         if (rc) return rc;
-        rc = run_cross_kv(h, n, t);
+        rc = run_cross_kv(h, n, t, gr);
         if (rc) return rc;
     }
     const int K = h->K, R = n * K;
