@@ -1,6 +1,6 @@
 """Development probe (GPU box): Model.predict_batches - the path under Evaluator.translate - on 16 host batches of 64 x 10 s
 utterances (stacked features on the host, H2D inside), for the test.engines_per_gpu / test.merge_utts settings of INTEGRATION.md.
-    python tools/predict_batches_probe.py"""
+    python tools/predict_batches_probe.py [batches [engines,merge ...]]"""
 import os
 import sys
 import time
@@ -17,7 +17,8 @@ from asr_amd.model import Engine, Model  # noqa: E402
 
 
 def main():
-    nb = 16
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    settings = [(1, 0), (4, 0), (4, 128), (2, 128), (4, 256)] if len(sys.argv) < 3 else [tuple(int(x) for x in a.split(',')) for a in sys.argv[2:]]
     base = bench.bench_config(10, 200, 'f32_f16x3', 3900)
     W = weights.random_init(base, seed=0)
     e0 = Engine(base, 0)
@@ -26,7 +27,7 @@ def main():
     one = np.stack([e0.stack_frames(rng.standard_normal((1000, 80)).astype(np.float32)) for _ in range(64)])
     e0.close()
     batches = [np.ascontiguousarray(np.roll(one, i, axis=0)) for i in range(nb)]
-    for engines, merge in [(1, 0), (4, 0), (4, 128), (2, 128), (4, 256)]:
+    for engines, merge in settings:
         cfg = bench.bench_config(10, 200, 'f32_f16x3', 3900)
         cfg.test['engines_per_gpu'] = engines
         cfg.test['merge_utts'] = merge or None
