@@ -69,6 +69,8 @@ def _load():
         'asr_last_error': (C.c_char_p, [vp]),
         'asr_load_tensor': (i32, [vp, C.c_char_p, f32p, i64p, i32]),
         'asr_finalize_weights': (i32, [vp]),
+        'asr_share_weights': (i32, [vp, vp]),
+        'asr_set_sharing': (i32, [vp, i32, i32]),
         'asr_decode': (i32, [vp, f32p, i32, i32, i32, i32p, i64, i32p]),
         'asr_decode_dev': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32p, i64, i32p]),
         'asr_loss': (i32, [vp, f32p, i32, i32, i32, i32p, i32, C.POINTER(C.c_double)]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 
 #define ASR_D_HEAD 64          // hidden_units / num_heads of every reference config
 #define ASR_MAX_BEAM 32

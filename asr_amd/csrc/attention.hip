@@ -821,14 +821,14 @@ template <int NB, bool KV16>
 hipError_t launch_self(const SelfAttnArgs& a, size_t lds, hipStream_t s)
 {
     auto kern = decoder_self_attention_kernel<NB, KV16>;
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];      // zero-initialised; several handles' host threads may launch first at once (the call is idempotent)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            150 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(a.heads, a.b), dim3(256), lds, s, a);
     return hipGetLastError();

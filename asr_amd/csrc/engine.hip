@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -31,6 +32,23 @@ constexpr int MAX_DEVICES = 64;
 constexpr int MAX_VIEWS = 4;        // sub-batches a beam search may run as (asr_config.sub_batches)
 static __device__ __align__(256) double g_norm_scratch[NOALLOC_MAX_UTTS * NOALLOC_DOUBLES_PER_UTT];
 double* g_norm_scratch_ptr[MAX_DEVICES] = {};      // device address of g_norm_scratch on device d (null: not resolved yet)
+std::mutex g_norm_scratch_mu[MAX_DEVICES];         // held while a device's entry is resolved (asr_create) and, by the allocation-free
+                                                   // entry point, from its launch to the end of its wait: handles of one GPU on
+                                                   // several host threads (EnginePool) take turns on that GPU's one array
+
+// The packed weights of one checkpoint on one GPU.  Handles of one GPU may share a store (asr_share_weights): the planes are
+// read-only once asr_finalize_weights has returned, so an EnginePool of four handles holds them once instead of four times.
+struct WeightStore {
+    int device = 0;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    ~WeightStore()
+    {
+        if (allocs.empty()) return;
+        (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+    }
+};
 
 struct HostTensor {
     std::vector<float> data;
@@ -80,8 +98,11 @@ struct asr_handle {
     std::map<std::string, HostTensor> staged;
     bool finalized = false;
 
-    std::map<void*, size_t> allocs;     // everything hipMalloc'ed through dev_alloc -> bytes
+    std::map<void*, size_t> allocs;     // everything hipMalloc'ed through dev_alloc -> bytes (the handle's own: caches, workspaces)
     int64_t dev_bytes = 0;
+    std::shared_ptr<WeightStore> wstore;    // the weights (asr_finalize_weights fills one; asr_share_weights adopts another handle's)
+    bool wstore_filling = false;        // dev_alloc books into the store (only while asr_finalize_weights uploads)
+    bool wstore_owner = false;          // this handle created the store: asr_device_bytes counts it here and nowhere else
 
     // weights
     float *w_src = nullptr, *b_src = nullptr, *in_gamma = nullptr, *in_beta = nullptr;
@@ -165,6 +186,11 @@ int dev_alloc(asr_handle* h, void** p, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
     HIP_TRY(h, hipMalloc(p, bytes));
+    if (h->wstore_filling && h->wstore) {
+        h->wstore->allocs.push_back(*p);
+        h->wstore->bytes += (int64_t)bytes;
+        return ASR_OK;
+    }
     h->allocs[*p] = bytes;
     h->dev_bytes += (int64_t)bytes;
     return ASR_OK;
@@ -1231,12 +1257,15 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     };
     hipError_t e;
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return hip_fail(e, "hipSetDevice");
-    if (!g_norm_scratch_ptr[cfg->device]) {                 // once per device, with that device current
-        double* p = nullptr;
-        if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_norm_scratch))) != hipSuccess)
-            return hip_fail(e, "hipGetSymbolAddress(g_norm_scratch)");
-        if (!p) return hip_fail(hipErrorInvalidSymbol, "hipGetSymbolAddress(g_norm_scratch)");
-        g_norm_scratch_ptr[cfg->device] = p;
+    {                                                       // once per device, with that device current
+        std::lock_guard<std::mutex> lock(g_norm_scratch_mu[cfg->device]);
+        double* p = g_norm_scratch_ptr[cfg->device];
+        if (!p) {
+            if ((e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_norm_scratch))) != hipSuccess)
+                return hip_fail(e, "hipGetSymbolAddress(g_norm_scratch)");
+            if (!p) return hip_fail(hipErrorInvalidSymbol, "hipGetSymbolAddress(g_norm_scratch)");
+            g_norm_scratch_ptr[cfg->device] = p;
+        }
     }
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->range_flag), 16)) != hipSuccess) return hip_fail(e, "hipMalloc");
@@ -1354,6 +1383,12 @@ int asr_finalize_weights(asr_handle* h)
         }
         if (!fits) h->nprod = h->nprod_active = 6;
     }
+    // everything uploaded from here to the end of the variable table goes into the handle's weight store
+    h->wstore = std::make_shared<WeightStore>();
+    h->wstore->device = h->cfg.device;
+    h->wstore_owner = true;
+    struct Filling { asr_handle* h; ~Filling() { h->wstore_filling = false; } } filling{h};
+    h->wstore_filling = true;
     if ((rc = upload_gemm(h, "encoder/src_change/kernel", &h->w_src))) return rc;
     if ((rc = upload(h, "encoder/src_change/bias", &h->b_src))) return rc;
     if ((rc = upload(h, "encoder/LayerNorm/gamma", &h->in_gamma))) return rc;
@@ -1406,9 +1441,48 @@ int asr_finalize_weights(asr_handle* h)
         if ((rc = upload(h, p + "/layer_norm_2/layer_norm_scale", &b.ln2s))) return rc;
         if ((rc = upload(h, p + "/layer_norm_2/layer_norm_bias", &b.ln2b))) return rc;
     }
+    h->wstore_filling = false;
     h->staged.clear();
     if ((rc = ensure_pe(h, h->cfg.max_target_length + 2))) return rc;
     h->finalized = true;
+    return ASR_OK;
+}
+
+// The handles of one GPU share one copy of the packed weights (include/asr_amd.h): `h` adopts the store `from` filled.
+int asr_share_weights(asr_handle* h, asr_handle* from)
+{
+    if (!h || !from || h == from) return h ? fail(h, ASR_ERR_ARG, "asr_share_weights needs two different handles") : ASR_ERR_ARG;
+    if (h->finalized) return fail(h, ASR_ERR_STATE, "weights already finalized");
+    if (!from->finalized || !from->wstore) return fail(h, ASR_ERR_STATE, "the other handle holds no finalized weights");
+    const asr_config &a = h->cfg, &b = from->cfg;
+    if (a.device != b.device) return fail(h, ASR_ERR_ARG, "handles of different GPUs cannot share weights");
+    if (a.input_dim != b.input_dim || a.hidden_units != b.hidden_units || a.num_heads != b.num_heads || a.num_blocks != b.num_blocks ||
+        a.dst_vocab_size != b.dst_vocab_size || a.ff_activation != b.ff_activation ||
+        (a.tie_embedding_and_softmax != 0) != (b.tie_embedding_and_softmax != 0) || a.precision != b.precision)
+        return fail(h, ASR_ERR_ARG, "handles with different model shapes or precision modes cannot share weights");
+    h->wstore = from->wstore;
+    h->wstore_owner = false;
+    h->nprod = from->nprod;                                 // (a checkpoint outside fp16's range has moved the owner to bf16x6)
+    h->nprod_active = h->nprod;
+    h->w_src = from->w_src; h->b_src = from->b_src; h->in_gamma = from->in_gamma; h->in_beta = from->in_beta;
+    h->emb = from->emb; h->softmax_w = from->softmax_w; h->emb_gemm = from->emb_gemm;
+    h->enc = from->enc; h->dec = from->dec;
+    h->staged.clear();
+    int rc = set_device(h);
+    if (rc) return rc;
+    if ((rc = ensure_pe(h, h->cfg.max_target_length + 2))) return rc;
+    h->finalized = true;
+    return ASR_OK;
+}
+
+// Regime of the calls that follow (include/asr_amd.h): what asr_config.shared_gpu / sub_batches set at creation.
+int asr_set_sharing(asr_handle* h, int32_t shared_gpu, int32_t sub_batches)
+{
+    if (!h) return ASR_ERR_ARG;
+    if ((shared_gpu != 0 && shared_gpu != 1) || sub_batches < 0 || sub_batches > MAX_VIEWS)
+        return fail(h, ASR_ERR_ARG, "shared_gpu must be 0 or 1, sub_batches 0 (automatic) or 1..4");
+    h->shared_gpu = shared_gpu != 0;
+    h->sub_batches = sub_batches;
     return ASR_OK;
 }
 
@@ -1920,15 +1994,18 @@ int asr_op_decoder_self_attention(asr_handle* h, const float* qkv, const float* 
                         put(kc, dst, hist_k[src]); put(vc, dst, hist_v[src]);
                     }
     std::vector<int32_t> anc_w((size_t)n * K * width, 0), live((size_t)n * K * width, 0), live_cnt(n, 0);
-    for (int u = 0; u < n; ++u) {
-        std::vector<char> seen((size_t)std::max(pos, 1) * 32, 0);
-        for (int b = 0; b < K; ++b)
-            for (int j = 0; j < pos; ++j) {
+    // the live list in the order beam_step_kernel writes it: by position, and within a position by ascending slot
+    for (int u = 0; u < n; ++u)
+        for (int j = 0; j < pos; ++j) {
+            uint32_t mask = 0;
+            for (int b = 0; b < K; ++b) {
                 const int sl = anc[((size_t)u * K + b) * pos + j];
                 anc_w[((size_t)u * K + b) * width + j] = sl;
-                if (!seen[(size_t)j * 32 + sl]) { seen[(size_t)j * 32 + sl] = 1; live[(size_t)u * K * width + live_cnt[u]++] = (j << 5) | sl; }
+                mask |= 1u << sl;
             }
-    }
+            for (int sl = 0; sl < 32; ++sl)
+                if (mask & (1u << sl)) live[(size_t)u * K * width + live_cnt[u]++] = (j << 5) | sl;
+        }
     TmpBufs tb;
     float *dqkv, *dbias, *dctx;
     char *dk, *dv;
@@ -2016,6 +2093,8 @@ int asr_op_input_norm_timing_noalloc(asr_handle* h, const float* x_dev, const fl
         return fail(h, ASR_ERR_CAPACITY, "static scratch too small");
     // Nothing in the scratch has to start at zero: the first statistics kernel writes every slot the later ones read
     // (rowops.hip input_norm_stats_kernel), so the previous call's contents are simply overwritten.
+    // One array per GPU: handles of that GPU on other host threads wait here for their turn (the call blocks anyway).
+    std::lock_guard<std::mutex> lock(g_norm_scratch_mu[h->cfg.device]);
     HIP_TRY(h, launch_input_norm_timing(x_dev, gamma_dev, beta_dev, h->pe, n, t, hidden, scratch, y_dev, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return ASR_OK;
@@ -2157,7 +2236,11 @@ int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, 
     return ASR_OK;
 }
 
-int64_t asr_device_bytes(const asr_handle* h) { return h ? h->dev_bytes : 0; }
+int64_t asr_device_bytes(const asr_handle* h)
+{
+    if (!h) return 0;
+    return h->dev_bytes + ((h->wstore && h->wstore_owner) ? h->wstore->bytes : 0);
+}
 
 int64_t asr_range_retries(const asr_handle* h) { return h ? h->range_retries : 0; }
 
@@ -2165,8 +2248,8 @@ int64_t asr_range_retries(const asr_handle* h) { return h ? h->range_retries : 0
 uint32_t asr_crc32c(const void* data, int64_t n, uint32_t crc)
 {
     static uint32_t T[8][256];
-    static bool init = false;
-    if (!init) {
+    static std::once_flag init;
+    std::call_once(init, [] {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
@@ -2174,8 +2257,7 @@ uint32_t asr_crc32c(const void* data, int64_t n, uint32_t crc)
         }
         for (uint32_t i = 0; i < 256; ++i)
             for (int s = 1; s < 8; ++s) T[s][i] = (T[s - 1][i] >> 8) ^ T[0][T[s - 1][i] & 0xFF];
-        init = true;
-    }
+    });
     const uint8_t* p = static_cast<const uint8_t*>(data);
     uint32_t c = ~crc;
     while (n >= 8) {

@@ -268,14 +268,14 @@ hipError_t launch_tile_impl(const GemmArgs& a, hipStream_t s)
     kchunk = (kchunk + KG - 1) / KG * KG;
     const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(f32x4);
     auto kern = gemm_f32_nt_kernel<BM, BN, WM, WN, EPI, MODE>;
-    static bool attr_done[64] = {};   // per instantiation, per device
+    static std::atomic<bool> attr_done[64];      // zero-initialised; several handles' host threads may launch first at once (the call is idempotent)   // per instantiation, per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     dim3 grid(nt_m * nt_n, split, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, nt_m, nt_n, kchunk);

@@ -381,13 +381,13 @@ hipError_t launch_split_tile(const GemmArgs& a, hipStream_t s)
     kchunk = (kchunk + SBK - 1) / SBK * SBK;
     const size_t lds = (size_t)2 * NPL * AR * 4 * sizeof(u32x4);
     auto kern = gemm_split_nt_kernel<MI, NI, NW, EPI, NPROD>;
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];      // zero-initialised; several handles' host threads may launch first at once (the call is idempotent)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(nt_m * nt_n, split, 1), dim3(NW * 64), lds, s, a, nt_m, nt_n, kchunk);
     return hipGetLastError();

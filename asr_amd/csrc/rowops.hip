@@ -858,14 +858,14 @@ hipError_t launch_log_softmax_topk(const float* logits, int nsplit, size_t split
 #undef TOPK_REG
         return hipGetLastError();
     }
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];      // zero-initialised; several handles' host threads may launch first at once (the call is idempotent)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_done[dev]) {
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(log_softmax_topk_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(log_softmax_topk_kernel, dim3(rows), dim3(256), lds, s, logits, nsplit, split_stride, vocab, k, values, indices, done);
     return hipGetLastError();

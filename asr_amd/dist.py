@@ -8,7 +8,44 @@ fixed-width int32 buffer per evaluation restores the original utterance order.  
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
+
+
+def world():
+    """(world_size, rank) of this process: the initialised torch.distributed group, else the launcher's environment
+    (`python -m torch.distributed.run`, `bench.py --gpus N`: WORLD_SIZE / RANK), else (1, 0)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank()
+    except ImportError:
+        pass
+    return int(os.environ.get('WORLD_SIZE', '1') or 1), int(os.environ.get('RANK', '0') or 0)
+
+
+def init_from_env():
+    """One process per GPU: join the process group the launcher described (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE).
+    Backend "nccl" (= RCCL over xGMI) with this rank's GPU (LOCAL_RANK) as its device; ASR_AMD_DIST_BACKEND=gloo keeps the
+    exchange on host tensors (CPU tests, several ranks rehearsed on one GPU).  Returns the torch device gathered buffers
+    must live on (None = host).  No-op (None) for a single process."""
+    n, _ = world()
+    if n <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get('ASR_AMD_DIST_BACKEND', 'nccl')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if backend == 'gloo':
+        if not dist.is_initialized():
+            dist.init_process_group(backend='gloo')
+        return None
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0') or 0))
+    torch.cuda.set_device(dev)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, device_id=dev)
+    return dev
 
 
 def bucket_batches(lengths, tokens_per_batch, bucket_min=50, bucket_max=10000, bucket_step=10):
@@ -186,3 +223,31 @@ def decode_sharded(decode_fn, feats, tokens_per_batch, beam, max_target_length, 
             ids.append(i)
             hyps.append(results[bi][r])
     return gather_hypotheses(ids, hyps, len(feats), max_target_length + 1, group=group, device=device)
+
+
+def predict_batches_sharded(batches, predict_batches, beam, max_target_length, rank=0, world_size=1, group=None, device=None):
+    """The multi-process form of `Model.predict_batches`: `batches` is the list of feature batches X [n_b, T_b, D] exactly as
+    the single-process reader yields them (the SAME list on every rank: batch composition and padding decide the
+    hypotheses, Q1 / Q7), whole batches are dealt to the ranks by cost, this rank's batches go through
+    `predict_batches(iterable of X) -> iterable of Y` (so `test.engines_per_gpu` / `test.merge_utts` apply per rank), and ONE
+    all_gather of a fixed-width int32 buffer brings every hypothesis to every rank (= the pad-with-3 + concat of
+    model.py:192-201).  Entries of `batches` this rank does not own may be replaced by their shapes (n_b, T_b).
+    Returns the list of Y per batch, int32 [n_b, max_target_length + 1] padded with 3, identical on every rank."""
+    shapes = [(b[0], b[1]) if isinstance(b, tuple) else (b.shape[0], b.shape[1]) for b in batches]
+    costs = [batch_cost(n, t, beam, max_target_length) for n, t in shapes]
+    mine = assign_batches(costs, world_size)[rank] if world_size > 1 else list(range(len(batches)))
+    first = np.concatenate([[0], np.cumsum([n for n, _ in shapes])]).astype(np.int64)
+    for bi in mine:
+        if isinstance(batches[bi], tuple):
+            raise ValueError('batch %d belongs to rank %d but only its shape was kept' % (bi, rank))
+    ids, hyps = [], []
+    for bi, Y in zip(mine, predict_batches(batches[bi] for bi in mine)):
+        if len(Y) != shapes[bi][0]:
+            raise RuntimeError('predict_batches returned %d rows for a batch of %d' % (len(Y), shapes[bi][0]))
+        for r in range(len(Y)):
+            ids.append(int(first[bi]) + r)
+            hyps.append(Y[r])
+    if len(ids) != sum(shapes[bi][0] for bi in mine):
+        raise RuntimeError('predict_batches ended early')
+    allh = gather_hypotheses(ids, hyps, int(first[-1]), max_target_length + 1, group=group, device=device)
+    return [allh[first[bi]:first[bi + 1]] for bi in range(len(batches))]

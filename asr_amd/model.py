@@ -15,7 +15,7 @@ import threading
 
 import numpy as np
 
-from . import _lib
+from . import _lib, hwqueues
 from ._lib import lib
 from .utils import shard_bounds
 
@@ -71,6 +71,7 @@ class Engine(object):
         self.cfg = c
         self.device = int(device)
         self._h = C.c_void_p()
+        hwqueues.mark_gpu_started()
         rc = lib.asr_create(C.byref(c), C.byref(self._h))
         _lib.check(None, rc)
         self.hidden = c.hidden_units
@@ -104,6 +105,16 @@ class Engine(object):
             shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
             _lib.check(self._h, lib.asr_load_tensor(self._h, name.encode('utf-8'), _lib.fptr(a), shape, a.ndim))
         _lib.check(self._h, lib.asr_finalize_weights(self._h))
+
+    def share_weights(self, other):
+        """Use the packed device weights `other` (a finalized Engine of the same GPU, model shape and precision) holds,
+        instead of load_weights: one copy per GPU for all handles of a pool (`asr_share_weights`)."""
+        _lib.check(self._h, lib.asr_share_weights(self._h, other._h))
+
+    def set_sharing(self, shared_gpu, sub_batches):
+        """Regime of the calls that follow (`asr_set_sharing`): shared_gpu 1 = other handles decode on this GPU at the same
+        time; sub_batches 0 = automatic, 1..4 = parts of a batch on their own streams."""
+        _lib.check(self._h, lib.asr_set_sharing(self._h, int(shared_gpu), int(sub_batches)))
 
     # ---- the hot path ---------------------------------------------------------------------------
     def decode(self, X):
@@ -166,13 +177,15 @@ class Engine(object):
                                                _lib.iptr(Y), Y.size, C.byref(ln)))
         return np.ascontiguousarray(Y.reshape(-1)[:n * ln.value].reshape(n, ln.value))
 
-    def decode_trace(self, X, trace_steps):
+    def decode_trace(self, X, trace_steps, logits=True):
+        """decode + the first `trace_steps` steps' pruned scores / tokens / parents (global row indices) and, unless
+        logits=False, the pre-softmax logits [steps, rows, vocab] (asr_decode_trace; one run of kernels, no graph replay)."""
         X = _lib.f32(X)
         n, t, d = X.shape
         R = n * self.beam
         Y = np.empty((n, self.max_len), np.int32)
         ln = C.c_int32(0)
-        logits = np.zeros((trace_steps, R, self.vocab), np.float32)
+        logits = np.zeros((trace_steps, R, self.vocab), np.float32) if logits else None
         scores = np.zeros((trace_steps, R), np.float32)
         tokens = np.zeros((trace_steps, R), np.int32)
         parents = np.zeros((trace_steps, R), np.int32)
@@ -271,6 +284,7 @@ class Engine(object):
 
 
 def visible_devices():
+    hwqueues.mark_gpu_started()
     return int(lib.asr_device_count())
 
 
@@ -295,29 +309,68 @@ class EnginePool(object):
     Unless the YAML sets `test.sub_batches`, the handles of a pool of two or more run each batch as ONE run of
     whole-batch kernels (the batches themselves are what overlaps)."""
 
+    # (class-level defaults: a pool assembled around stand-in handles, as the CPU tests do, has one regime)
+    _alone = _together = _regime = (0, 0)
+    _regime_users = 0
+    _regime_lock = threading.Lock()
+
     def __init__(self, config, device=0, engines=2):
-        import copy
         n = max(1, int(engines))
-        cfg = config
-        if n > 1:
-            cfg = copy.deepcopy(config)
-            if config.test.sub_batches is None and not os.environ.get('ASR_AMD_SUBBATCH'):
-                cfg.test['sub_batches'] = 1
-            if config.test.shared_gpu is None:
-                cfg.test['shared_gpu'] = 1
-        if n >= 4 and not os.environ.get('GPU_MAX_HW_QUEUES'):
-            # a handle per hardware queue (the runtime's default is four queues per process, and the streams of a fourth
-            # handle then share one).  Read by the HIP runtime when the process first touches the GPU: no effect later.
-            os.environ['GPU_MAX_HW_QUEUES'] = '8'
-        self.engines = [Engine(cfg, device) for _ in range(n)]
+        t = config.test
+        env_sb = int(os.environ.get('ASR_AMD_SUBBATCH') or 0)
+        # the regime of a handle used ALONE (Model.predict, Evaluator.loss, a pool of one): what the YAML says, else the
+        # library's defaults (K-slices and tiles that fill the chip by themselves, two half batches from 320 beam rows)
+        self._alone = (1 if t.shared_gpu else 0, int(t.sub_batches or env_sb or 0))
+        # ... and while the pool's handles decode side by side (map): fewer K-slices, every batch ONE run of kernels
+        self._together = (1 if (t.shared_gpu is None or t.shared_gpu) else 0, int(t.sub_batches or env_sb or 1))
+        self._regime = self._alone
+        self._regime_lock = threading.Lock()
+        self._regime_users = 0
+        if n >= 4:
+            # a hardware queue per handle (asr_amd/hwqueues.py); has to happen before the process first touches the GPU
+            self.hw_queues = hwqueues.ensure()
+        else:
+            self.hw_queues = {'value': hwqueues.current(), 'source': 'not changed (fewer than four handles)', 'late': False}
+        self.engines = [Engine(config, device) for _ in range(n)]
 
     def load_weights(self, variables):
-        for e in self.engines:
-            e.load_weights(variables)
+        """The first handle packs and uploads the checkpoint; the others share its device copy (read-only planes)."""
+        self.engines[0].load_weights(variables)
+        for e in self.engines[1:]:
+            e.share_weights(self.engines[0])
+
+    def device_bytes(self):
+        return sum(e.device_bytes() for e in self.engines)
 
     def close(self):
         for e in self.engines:
             e.close()
+
+    def together(self):
+        """Context manager: the pool's handles are in the shared-GPU regime inside (nestable, thread-safe); `map` uses it.
+        Outside, every handle is in the regime of a handle that has the GPU to itself."""
+        pool = self
+
+        class _Together(object):
+            def __enter__(self):
+                with pool._regime_lock:
+                    pool._regime_users += 1
+                    if pool._regime_users == 1 and len(pool.engines) > 1 and pool._together != pool._alone:
+                        for e in pool.engines:
+                            e.set_sharing(*pool._together)
+                        pool._regime = pool._together
+                return pool
+
+            def __exit__(self, *exc):
+                with pool._regime_lock:
+                    pool._regime_users -= 1
+                    if pool._regime_users == 0 and pool._regime != pool._alone:
+                        for e in pool.engines:
+                            if getattr(e, '_h', None):
+                                e.set_sharing(*pool._alone)
+                        pool._regime = pool._alone
+                return False
+        return _Together()
 
     def map(self, call, items):
         """Ordered iterator over call(engine, item) for item in items, with as many items in flight as there are
@@ -365,6 +418,8 @@ class EnginePool(object):
                     st['results'][idx] = r
                     cond.notify_all()
         threads = [threading.Thread(target=worker, args=(e,), daemon=True) for e in self.engines]
+        regime = self.together()
+        regime.__enter__()
         for th in threads:
             th.start()
         try:
@@ -386,6 +441,7 @@ class EnginePool(object):
                 cond.notify_all()
             for th in threads:
                 th.join()
+            regime.__exit__(None, None, None)
 
     def decode_many(self, batches):
         """Y of every X in `batches`, in order."""
@@ -404,14 +460,26 @@ class Model(object):
     def __init__(self, config, num_gpus, devices=None):
         self._config = config
         self._num_towers = max(int(num_gpus or 0), 1)            # model.py:27: 0 GPUs -> one CPU tower
+        # build extension (not a reference key): engine handles per GPU, see EnginePool.  Unset, with one tower: the measured
+        # optimum for whole test sets (`predict_batches`, i.e. Evaluator.translate) - four handles when the process has, or
+        # can still get, eight hardware queues, three on the runtime's default four; `predict` / `loss` use the first
+        # handle alone in either case.  Decided BEFORE the first GPU call of this process (asr_amd/hwqueues.py).
+        epg = (config.test.engines_per_gpu if config.test else None) or os.environ.get('ASR_AMD_ENGINES')
+        if epg:
+            self._engines_per_gpu = max(1, int(epg))
+        elif self._num_towers == 1:
+            q = hwqueues.ensure()
+            self._engines_per_gpu = 4 if q['value'] >= hwqueues.WANTED else 3
+            logging.info('asr_amd: test.engines_per_gpu unset: %d engine handles per GPU on %d hardware queues (%s)',
+                         self._engines_per_gpu, q['value'], q['source'])
+        else:
+            self._engines_per_gpu = 1
         if devices is None:
             if 'LOCAL_RANK' in os.environ or 'ASR_AMD_DEVICE' in os.environ:
                 devices = [default_device()]
             else:
                 devices = list(range(max(1, min(self._num_towers, visible_devices()))))
         self._devices = list(devices)
-        # build extension (not a reference key): engine handles per GPU, see EnginePool
-        self._engines_per_gpu = max(1, int((config.test.engines_per_gpu if config.test else None) or os.environ.get('ASR_AMD_ENGINES') or 1))
         self.pools = []
         self.engines = []
         self.encoder_scope = 'encoder'

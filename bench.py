@@ -11,6 +11,11 @@ max_target_length 200, 64 synthetic 10-second utterances per GPU per step.
 One process per GPU; every rank decodes its own 64-utterance batch per step (weak scaling, utterances are
 independent), then the step's hypotheses are gathered with one RCCL all_gather of a fixed-width int32
 buffer (the path's only exchange, model.py:192-201).  Rank 0 prints ONE JSON line.
+`python bench.py --gpus N` with N > 1 and no launcher (no RANK in the environment) starts the N ranks ITSELF: the parent
+imports neither torch nor the HIP library, gives each child RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT,
+relays rank 0's JSON line and exits non-zero when any rank fails.  Under an external launcher WORLD_SIZE must equal
+--gpus (anything else is an error, never a silent one-GPU run).  `--dry-launch` rehearses only that plumbing: every
+child joins a gloo group, the ranks are all-gathered, rank 0 prints {"dry_launch": true, "n_gpus": N, "ranks_seen": [...]}.
 A step = one 64-utterance batch through the whole path.  By default FOUR steps are in flight on every GPU
 (`--in-flight 4`: four engine handles, asr_amd.model.EnginePool, each decoding whole steps one after the other): the
 K timed steps are the same K batches decoded the same way, `ms_per_step` = elapsed / K; the line also carries
@@ -25,6 +30,10 @@ The same line also carries, at N = 1 (all timed by this run, on this box):
                       with the extrapolation to 201 steps by the algorithm's FLOP count stated
   alt_precisions      the other dense-layer arithmetics (f32_bf16x6, f32, bf16), a few steps each, with a flag saying
                       whether their hypotheses equal the headline mode's
+  configs             every BASELINE.json configuration timed by this same run (a few steps each): config 1 (8 ragged
+                      utterances, greedy; batch by batch and as one joint decode), 3 / 4 (512 ragged utterances through the
+                      10-frame buckets, V = 1388 / 28444, batch by batch and with joint decodes of 64), 5 (50 x 30 s, V = 3205,
+                      bf16 and the default mode), each with value, ms per step and a crc32 of its hypotheses
 
 `--workload bucketed` instead runs BASELINE configs 3/4 as stated: ragged utterances, 10-frame length buckets
 (utils.py:285-323), batches dealt over the ranks by cost, each rank decoding its share with the real engine, one
@@ -46,14 +55,13 @@ if ROOT not in sys.path:
 
 # Streams of one process share its hardware queues (4 by default) in creation order, and kernels of two streams that share
 # a queue do not overlap.  The benchmark keeps several engine handles busy on one GPU, each on a stream of its own, so it
-# asks the HIP runtime for 8 queues - before anything initialises it.  (Measured, 64-utterance steps: 3 handles on 4
-# queues 225 ms a step, 4 handles on 8 queues 214 ms; 4 handles on 4 queues 243 ms.)
-HW_QUEUES = 8
-try:
-    if int(os.environ.get('GPU_MAX_HW_QUEUES', '0') or 0) < HW_QUEUES:
-        os.environ['GPU_MAX_HW_QUEUES'] = str(HW_QUEUES)
-except ValueError:
-    os.environ['GPU_MAX_HW_QUEUES'] = str(HW_QUEUES)
+# asks the HIP runtime for 8 queues - before anything initialises it - by the policy the product path applies as well
+# (asr_amd/hwqueues.py, called by asr_amd.model.Model / EnginePool): a lower value is raised, ASR_AMD_KEEP_HW_QUEUES=1 keeps
+# what the environment says.  (Measured, 64-utterance steps: 3 handles on 4 queues 225 ms a step, 4 handles on 8 queues
+# 214 ms; 4 handles on 4 queues 243 ms.)
+from asr_amd import hwqueues  # noqa: E402  (pure Python: loads neither torch nor the HIP library)
+
+HWQ = hwqueues.ensure()
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: BF16 dense MFMA peak
@@ -180,6 +188,17 @@ def cpu_baseline_ref_shaped(cfg, W, raw, steps=20):
                       '(block-output cache, per-step re-projection), numpy/OpenBLAS float32' % (audio_s, cfg.test.beam_size, Y.shape[1])}
 
 
+def identical_to_oracle(Y, Yc):
+    """How many of the oracle's sample utterances (the first rows of the batch, decoded by the float32 CPU oracle as a batch
+    of their own - with equal-length utterances the padding, and with it Q1's statistics, are the same) the GPU reproduces
+    token for token.  Random-init weights over 201 steps leave near-ties (candidate totals closer than one float32 ulp of
+    the score): tests/test_gpu_near_tie.py shows, per differing utterance, that this is the only way they differ."""
+    if Yc is None:
+        return 0
+    m = min(Yc.shape[1], Y.shape[1])
+    return int(np.all(Yc[:, :m] == Y[:Yc.shape[0], :m], axis=1).sum())
+
+
 def roofline_of(prof, precision):
     overhead = [p for p in prof if p['name'].startswith('(')]
     prof = [p for p in prof if not p['name'].startswith('(')]
@@ -214,23 +233,26 @@ def roofline_of(prof, precision):
     return r, kernels
 
 
-def run_bucketed(args, rank, local_rank, world, rehearse):
-    """BASELINE configs 3/4: ragged utterances, length-bucketed batches sharded over the ranks (asr_amd/dist.py)."""
+def run_bucketed(args, rank, local_rank, world, rehearse, W=None):
+    """BASELINE configs 1 / 3 / 4: ragged utterances, length-bucketed batches sharded over the ranks (asr_amd/dist.py).
+    Returns the result line (a dict) on rank 0, None elsewhere."""
+    import threading
     import torch
     import torch.distributed as dist
     from asr_amd import dist as D
     from asr_amd import weights
-    from asr_amd.model import Engine
+    from asr_amd.model import EnginePool
 
     cfg = bench_config(args.beam, args.max_target_length, args.precision, args.vocab)
-    W = weights.random_init(cfg, seed=0)
-    engines = [Engine(cfg, local_rank) for _ in range(max(1, args.engines_per_gpu))]
-    for e in engines:
-        e.load_weights(W)
+    if W is None:
+        W = weights.random_init(cfg, seed=0)
+    pool = EnginePool(cfg, local_rank, max(1, args.engines_per_gpu))
+    pool.load_weights(W)
+    engines = pool.engines
     eng = engines[0]
     n_total = world * args.utts_per_gpu
     rng = np.random.default_rng(4242)                                  # every rank builds the same utterance list
-    raw_lens = [int(x) for x in rng.integers(200, 1501, size=n_total)]
+    raw_lens = [int(x) for x in rng.integers(args.t_raw_min, args.t_raw_max + 1, size=n_total)]
     # left3 / sub3 stacking by the library's own front-end kernel (fea.py:142-149), outside the timed region
     feats = [eng.stack_frames(rng.standard_normal((ln, 80)).astype(np.float32)) for ln in raw_lens]
     lengths = [len(f) for f in feats]
@@ -239,7 +261,6 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
     owners = D.assign_batches(costs, world)
     model_load = [sum(costs[i] for i in o) for o in owners]
     busy = [0.0]
-    import threading
     busy_lock = threading.Lock()
 
     def make_decode_fn(e):
@@ -255,8 +276,9 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
     device = None if (rehearse or world == 1) else torch.device('cuda', local_rank)
 
     def step():
-        return D.decode_sharded(decode_fns, feats, args.tokens_per_batch, args.beam, args.max_target_length, rank=rank,
-                                world_size=world, device=device, merge_utts=args.merge_utts)
+        with pool.together():
+            return D.decode_sharded(decode_fns, feats, args.tokens_per_batch, args.beam, args.max_target_length, rank=rank,
+                                    world_size=world, device=device, merge_utts=args.merge_utts)
 
     def fence():
         torch.cuda.synchronize()
@@ -273,15 +295,18 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
         Y = step()
     fence()
     elapsed = time.perf_counter() - t0
-    busy_all = [busy[0]]
+    busy_all, per_rank = [busy[0]], [elapsed]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        bt = torch.tensor([busy[0]], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
+        bt = torch.tensor([busy[0], elapsed, float(rank)], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
         parts = [torch.empty_like(bt) for _ in range(world)]
         dist.all_gather(parts, bt)
-        busy_all = [float(p.item()) for p in parts]
+        busy_all = [float(p[0].item()) for p in parts]
+        per_rank = [float(p[1].item()) for p in parts]
+        ranks_seen = sorted(int(p[2].item()) for p in parts)
+        elapsed = max(per_rank)
+    else:
+        ranks_seen = [0]
+    out = None
     if rank == 0:
         audio_s = sum(raw_lens) / 100.0 * args.steps
         out = {
@@ -289,34 +314,37 @@ def run_bucketed(args, rank, local_rank, world, rehearse):
             'value': audio_s / elapsed, 'unit': 'audio-sec/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1000.0 * elapsed / max(args.steps, 1), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': PRECISION_INFO[args.precision][0], 'data': 'synthetic',
-            'config': {'workload': 'bucketed: %d utterances per GPU, T_raw ~ U[200,1500] (%.0f audio-s in all), 10-frame length '
+            'config': {'workload': 'bucketed: %d utterances per GPU, T_raw ~ U[%d,%d] (%.0f audio-s in all), 10-frame length '
                                    'buckets closed above %d stacked frames (utils.py:285-323), %d batches dealt over %d rank(s) by '
                                    'cost and decoded by %d engine handle(s) per GPU side by side, host features (H2D inside the step), one all_gather of the hypotheses; char '
                                    'architecture with V=%d, beam %d, max_target_length %d, random-init weights'
-                                   % (args.utts_per_gpu, sum(raw_lens) / 100.0, args.tokens_per_batch, len(batches), world, len(engines), args.vocab,
-                                      args.beam, args.max_target_length),
+                                   % (args.utts_per_gpu, args.t_raw_min, args.t_raw_max, sum(raw_lens) / 100.0, args.tokens_per_batch, len(batches), world,
+                                      len(engines), args.vocab, args.beam, args.max_target_length),
                        'parallelism': 'dp%d' % world, 'precision': args.precision, 'batches': len(batches), 'engines_per_gpu': len(engines),
                        # > 0: a rank's batches joined into joint decodes of up to that many utterances (Engine.decode_groups)
                        'merge_utts': args.merge_utts,
                        'joint_decodes': [len(D.merge_jobs(o, [len(b) for b in batches], [max(lengths[i] for i in b) for b in batches],
                                                          args.merge_utts)) for o in owners],
                        'batch_sizes': sorted(len(b) for b in batches)[::max(1, len(batches) // 16)],
+                       'hw_queues': HWQ['value'], 'hw_queues_source': HWQ['source'],
                        'range_retries': eng.range_retries()},
             # per-rank seconds inside Engine.decode over the timed steps (summed over the rank's engine threads), and how even the deal was
             'per_rank_busy_s': [round(b, 4) for b in busy_all],
+            'per_rank_ms_per_step': [round(1000.0 * e / max(args.steps, 1), 3) for e in per_rank],
+            'ranks_seen': ranks_seen,
             'load_balance': {'measured_max_over_mean': max(busy_all) / (sum(busy_all) / len(busy_all)),
                              'cost_model_max_over_mean': max(model_load) / (sum(model_load) / len(model_load))},
             'hypotheses_shape': list(Y.shape),
             'hypotheses_crc32': int(__import__('zlib').crc32(np.ascontiguousarray(Y).tobytes())),   # same for any number of engines / ranks
         }
-        print(json.dumps(out), flush=True)
-    for e in engines:
-        e.close()
+    pool.close()
+    return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=1, help='ranks = GPUs of this node.  Without a launcher (no RANK in the environment) and N > 1 '
+                    'this process starts the N ranks itself; under torch.distributed.run WORLD_SIZE must equal it')
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=64)
@@ -329,6 +357,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-precisions', action='store_true')
     ap.add_argument('--no-one-at-a-time', action='store_true', help='skip the one_step_at_a_time leg (profiling runs)')
+    ap.add_argument('--no-configs', action='store_true', help='skip the `configs` leg (the other BASELINE configurations)')
     ap.add_argument('--alt-steps', type=int, default=8)
     ap.add_argument('--in-flight', type=int, default=4, help='steps (whole batches) being decoded at any time on one GPU, each by an '
                     'engine handle of its own (asr_amd.model.EnginePool); 1 = one step at a time')
@@ -338,20 +367,197 @@ def main():
     ap.add_argument('--merge-utts', type=int, default=0, help='--workload bucketed: join a rank\'s batches into joint decodes of up to this '
                     'many utterances (Engine.decode_groups); 0 = batch by batch like the reference\'s translate loop')
     ap.add_argument('--utts-per-gpu', type=int, default=512, help='--workload bucketed: utterances per GPU (a test set of a few hundred utterances fills the 10-frame buckets; 64 leaves mostly single-utterance batches)')
-    ap.add_argument('--engines-per-gpu', type=int, default=4, help='--workload bucketed: engine handles (weight replica, K/V cache, '
-                    'streams, one host thread each) that decode the rank\'s batches side by side')
+    ap.add_argument('--t-raw-min', type=int, default=200, help='--workload bucketed: raw frames per utterance ~ U[min, max]')
+    ap.add_argument('--t-raw-max', type=int, default=1500)
+    ap.add_argument('--engines-per-gpu', type=int, default=4, help='--workload bucketed: engine handles (K/V cache, '
+                    'streams, one host thread each; one shared copy of the weights) that decode the rank\'s batches side by side')
     ap.add_argument('--tokens-per-batch', type=int, default=7000, help='--workload bucketed: stacked frames per batch '
                     '(test.tokens_per_batch of the SEAME yaml)')
-    args = ap.parse_args()
+    ap.add_argument('--dry-launch', action='store_true', help='rehearse the multi-rank plumbing only: every rank joins a gloo group and '
+                    'reports its rank (no GPU, no HIP library)')
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args, argv):
+    """`--gpus N` with no launcher: start the N ranks, one process each.  This parent never imports torch and never touches
+    HIP (a process that has initialised the GPU must not be the one that spawns or re-execs others): it only spawns, relays
+    rank 0's stdout (the JSON line) and waits.  Any rank that exits non-zero ends the job: the others are terminated (by PID)
+    and the parent exits with that code."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    assert 'torch' not in sys.modules, 'the launching parent must not have imported torch'
+    n = args.gpus
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(n), 'LOCAL_WORLD_SIZE': str(n),
+                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, '-u', os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    lines = []
+
+    def relay():
+        for line in procs[0].stdout:
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+
+    def stop_all(code):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        return code
+    signal.signal(signal.SIGTERM, lambda *_: sys.exit(stop_all(143)))
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                print('bench.py: rank %d exited with code %d; stopping the other ranks' % bad[0], file=sys.stderr, flush=True)
+                return stop_all(bad[0][1] if bad[0][1] > 0 else 1)
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.2)
+    except KeyboardInterrupt:
+        return stop_all(130)
+    th.join(timeout=10.0)
+    got = None
+    for line in lines:
+        try:
+            d = json.loads(line)
+            if isinstance(d, dict) and 'n_gpus' in d:
+                got = d
+        except ValueError:
+            pass
+    if got is None or got.get('n_gpus') != n:
+        print('bench.py: rank 0 printed no result line with n_gpus == %d' % n, file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
+def dry_rank(args, rank, world):
+    """--dry-launch: the rank joins a gloo group, the ranks are all-gathered, rank 0 prints what it saw."""
+    if os.environ.get('ASR_BENCH_DRY_FAIL_RANK', '') == str(rank):      # test hook: a rank that dies before it joins
+        sys.exit(3)
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if world > 1:
+        dist.init_process_group(backend='gloo')
+        t = torch.tensor([rank], dtype=torch.int64)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        seen = sorted(int(p.item()) for p in parts)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = [0]
+    if rank == 0:
+        print(json.dumps({'dry_launch': True, 'n_gpus': world, 'ranks_seen': seen, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')),
+                          'master_port': os.environ.get('MASTER_PORT')}), flush=True)
+
+
+def _ns(args, **kw):
+    d = dict(vars(args))
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def measure_configs(args, local_rank, W_char):
+    """Every BASELINE.json configuration timed by this same run, a few steps each (the headline, config 2, is `value`).
+    Hypothesis crc32s: the same for any number of handles / ranks (every batch is decoded as alone); joint decodes change
+    the float32 summation order of the row-wise kernels."""
+    import zlib
+    import torch
+    from asr_amd import weights
+    from asr_amd.model import EnginePool
+    out = {}
+
+    # config 1: the reference's CPU-runnable case - 8 ragged utterances, greedy
+    c1 = dict(vocab=3900, beam=1, utts_per_gpu=8, t_raw_min=300, t_raw_max=1000, steps=3)
+    t0 = time.time()
+
+    def bucketed_w(name, what, W, **kw):
+        a = _ns(args, workload='bucketed', steps=kw.pop('steps', 2), warmup=1, engines_per_gpu=4, **kw)
+        r = run_bucketed(a, 0, local_rank, 1, False, W=W)
+        out[name] = {'what': what, 'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'], 'steps': a.steps,
+                     'precision': a.precision, 'batches': r['config']['batches'], 'merge_utts': a.merge_utts,
+                     'hypotheses_crc32': r['hypotheses_crc32']}
+    what1 = 'config 1: char V=3900, greedy (beam 1), 8 ragged utterances T_raw ~ U[300,1000], 10-frame buckets'
+    bucketed_w('config1_batch_by_batch', what1 + ', batch by batch on four handles', W_char, merge_utts=0, **c1)
+    bucketed_w('config1_merge_utts_8', what1 + ', one joint decode (--merge-utts 8)', W_char, merge_utts=8, **c1)
+    for name, vocab in (('config3_pinyin', 1388), ('config4_word', 28444)):
+        Wv = weights.random_init(bench_config(args.beam, args.max_target_length, args.precision, vocab), seed=0)
+        what = ('%s: V=%d, beam %d, 512 ragged utterances T_raw ~ U[200,1500] through the 10-frame buckets (46 batches), four handles'
+                % (name.replace('_', ' '), vocab, args.beam))
+        bucketed_w(name + '_batch_by_batch', what + ', batch by batch', Wv, vocab=vocab, merge_utts=0, utts_per_gpu=512)
+        bucketed_w(name + '_merge_utts_64', what + ', joint decodes of up to 64 utterances', Wv, vocab=vocab, merge_utts=64, utts_per_gpu=512)
+        del Wv
+    # config 5: SEAME vocabulary, 50 x 30 s, fixed batch, four steps in flight
+    n5, t5 = 50, 3000
+    raw5 = synthetic_raw(n5, t5, seed=5000)
+    d5 = torch.from_numpy(raw5).cuda(local_rank)
+    W5 = weights.random_init(bench_config(args.beam, args.max_target_length, 'bf16', 3205), seed=0)
+    for prec in ('bf16', args.precision):
+        p5 = EnginePool(bench_config(args.beam, args.max_target_length, prec, 3205), local_rank, 4)
+        p5.load_weights(W5)
+
+        def dec5(e, _=None):
+            return e.decode_dev(d5.data_ptr(), n5, 0, 0, raw=(t5, 80, 3, 0, 3))
+        for _ in p5.map(dec5, range(4)):
+            pass
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        k5 = 4
+        for Y5 in p5.map(dec5, range(k5)):
+            pass
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        out['config5_seame_30s_' + prec] = {
+            'what': 'config 5: SEAME V=3205, 50 x 30 s utterances (T=1000 stacked frames), beam %d, %d decode steps, four steps in flight' % (args.beam, Y5.shape[1]),
+            'value': n5 * t5 / 100.0 * k5 / dt, 'unit': 'audio-sec/sec', 'ms_per_step': 1000.0 * dt / k5, 'steps': k5, 'precision': prec,
+            'hypotheses_crc32': int(zlib.crc32(np.ascontiguousarray(Y5).tobytes()))}
+        p5.close()
+    out['seconds_spent'] = round(time.time() - t0, 1)
+    return out
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    launched = 'RANK' in os.environ
+    if not launched and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))                 # this process only spawns, relays and waits: no torch, no HIP
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d: the launcher must start exactly --gpus ranks (python -m torch.distributed.run '
+                 '--nproc-per-node N ... bench.py --gpus N); without a launcher `python bench.py --gpus N` starts the ranks itself'
+                 % (args.gpus, world))
+    if args.dry_launch:
+        dry_rank(args, rank, world)
+        return
 
     import torch
     import torch.distributed as dist
     from asr_amd import weights
-    from asr_amd.model import Engine
 
     # Rehearsal switch for a one-GPU box (never set by the driver): all ranks share GPU 0 and the gather runs over
     # gloo on host tensors, so the multi-rank plumbing can be exercised where RCCL cannot (two ranks on one device).
@@ -367,7 +573,9 @@ def main():
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
     if args.workload == 'bucketed':
-        run_bucketed(args, rank, local_rank, world, rehearse)
+        out = run_bucketed(args, rank, local_rank, world, rehearse)
+        if out is not None:
+            print(json.dumps(out), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -376,8 +584,9 @@ def main():
     from asr_amd.model import EnginePool
     cfg = bench_config(args.beam, args.max_target_length, args.precision, args.vocab)
     W = weights.random_init(cfg, seed=0)
-    # `--in-flight` engine handles on the GPU (asr_amd.model.EnginePool: own weight replica, K/V cache and streams, one host
-    # thread each): that many steps (whole 64-utterance batches) are being decoded at any time, each exactly as if alone
+    # `--in-flight` engine handles on the GPU (asr_amd.model.EnginePool: own K/V cache and stream, one host thread each, ONE
+    # shared copy of the weights): that many steps (whole 64-utterance batches) are being decoded at any time, each exactly
+    # as if alone
     pool = EnginePool(cfg, local_rank, args.in_flight)
     pool.load_weights(W)
     eng = pool.engines[0]
@@ -388,18 +597,21 @@ def main():
     torch.cuda.synchronize()
     width = args.max_target_length + 1
     front = (t_raw, 80, 3, 0, 3)
+    seen_ranks = [[0]]
 
     def decode(e, _=None):
         return e.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
 
-    def gather(Y):          # the hypotheses of a step (fixed width, padded with 3) on every rank: the path's only exchange
+    def gather(Y):          # the hypotheses of a step (fixed width, padded with 3; column 0 = the rank) on every rank: the path's only exchange
         if world > 1:
-            buf = torch.full((n, width), 3, dtype=torch.int32)
-            buf[:, :Y.shape[1]] = torch.from_numpy(Y)
+            buf = torch.full((n, width + 1), 3, dtype=torch.int32)
+            buf[:, 0] = rank
+            buf[:, 1:1 + Y.shape[1]] = torch.from_numpy(Y)
             if not rehearse:
                 buf = buf.cuda(local_rank)
             out = [torch.empty_like(buf) for _ in range(world)]
             dist.all_gather(out, buf)
+            seen_ranks[0] = sorted(set(int(o[0, 0].item()) for o in out))
 
     def run_steps(p, k):
         """k steps through pool p: results come back in step order on this thread, which gathers each while the
@@ -425,10 +637,13 @@ def main():
     # W untimed steps - and at least one on every handle, so that no handle's first call falls into the timed region
     Y = run_steps(pool, max(args.warmup, len(pool.engines)) if args.warmup > 0 else 0)
     elapsed, Y = timed(pool, args.steps)
+    per_rank = [elapsed]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        parts = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)
+        per_rank = [float(p.item()) for p in parts]
+        elapsed = max(per_rank)                              # the job is done when its slowest rank is
 
     if rank == 0:
         audio_s = world * n * t_raw / 100.0 * args.steps
@@ -448,10 +663,14 @@ def main():
                                        'other as one run of %d-row kernels; ms_per_step = elapsed / steps' % (nfl, nfl, n * args.beam))
                                       if nfl > 1 else 'one step at a time'),
                        'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world, 'precision': args.precision,
-                       'steps_in_flight': nfl, 'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')),
+                       'steps_in_flight': nfl, 'hw_queues': HWQ['value'], 'hw_queues_source': HWQ['source'],
                        # precision f32_f16x3: calls the library repeated on the bf16x6 kernels because an operand left
                        # fp16's range (0 = every timed step ran on the fp16x3 kernels)
-                       'range_retries': sum(e.range_retries() for e in pool.engines)},
+                       'range_retries': sum(e.range_retries() for e in pool.engines),
+                       'device_bytes_of_the_pool': pool.device_bytes()},
+            # every rank's own clock over the timed steps, and the ranks whose rows arrived in the last step's all_gather
+            'per_rank_ms_per_step': [round(1000.0 * e / max(args.steps, 1), 3) for e in per_rank],
+            'ranks_seen': seen_ranks[0],
         }
         # ---- roofline of the dominant kernel: HIP events around every launch of one extra step on the first handle, on the
         # stream each kernel is launched on, left in the queues and read back afterwards (profile mode 2), while the
@@ -459,18 +678,19 @@ def main():
         # rocprofv3 --kernel-trace reports for this command.  A second step with every bracket waited for and nothing
         # beside it (mode 1) gives each kernel alone on the GPU: `solo_us` ----
         import threading
-        eng.set_profile(2)
-        others = [threading.Thread(target=lambda e=e: [decode(e) for _ in range(2)]) for e in pool.engines[1:]]
-        for th in others:
-            th.start()
-        decode(eng)
-        prof = eng.get_profile()
-        for th in others:
-            th.join()
-        eng.set_profile(1)
-        decode(eng)
-        solo = {p['name']: p for p in eng.get_profile()}
-        eng.set_profile(0)
+        with pool.together():                     # the regime of the timed region (EnginePool.map enters it by itself)
+            eng.set_profile(2)
+            others = [threading.Thread(target=lambda e=e: [decode(e) for _ in range(2)]) for e in pool.engines[1:]]
+            for th in others:
+                th.start()
+            decode(eng)
+            prof = eng.get_profile()
+            for th in others:
+                th.join()
+            eng.set_profile(1)
+            decode(eng)
+            solo = {p['name']: p for p in eng.get_profile()}
+            eng.set_profile(0)
         out['roofline'], out['kernels'] = roofline_of(prof, args.precision)
         for k in out['kernels']:
             p1 = solo.get(k['name'])
@@ -505,10 +725,11 @@ def main():
             ws['pmc_traffic_gbs'] = ws['pmc_traffic_gb'] / step_s
             ws['pmc_traffic_frac_of_hbm_peak'] = ws['pmc_traffic_gbs'] / PEAK_HBM_GBS
         rf['whole_step'] = {k: round(v, 4) for k, v in ws.items()}
+        Yc = None
         if world == 1 and not args.no_cpu_baseline:
             cb, Yc = cpu_baseline(cfg, W, raw, min(args.cpu_sample_utts, n))
-            m = min(Yc.shape[1], Y.shape[1])
-            cb['hypotheses_match_gpu'] = bool(np.array_equal(Yc[:, :m], Y[:Yc.shape[0], :m]))
+            cb['hypotheses_match_gpu'] = bool(identical_to_oracle(Y, Yc) == Yc.shape[0])
+            cb['utterances_identical_to_oracle'] = '%d of %d' % (identical_to_oracle(Y, Yc), Yc.shape[0])
             out['cpu_baseline'] = cb
             out['cpu_baseline_ref_shaped'] = cpu_baseline_ref_shaped(cfg, W, raw)
         pool.close()
@@ -572,8 +793,12 @@ def main():
                               # leave near-ties, so one f32-rounding-level difference can turn an utterance's beam
                               'hypotheses_match': bool(Ya.shape == Y.shape and same.all()),
                               'utterances_identical': '%d of %d' % (int(same.sum()), n)}
+                if Yc is not None:
+                    alts[prec]['utterances_identical_to_oracle'] = '%d of %d' % (identical_to_oracle(Ya, Yc), Yc.shape[0])
                 p2.close()
             out['alt_precisions'] = alts
+        if world == 1 and not args.no_configs and args.vocab == 3900 and args.precision == 'f32_f16x3':
+            out['configs'] = measure_configs(args, local_rank, W)
         print(json.dumps(out), flush=True)
 
     if pool is not None:

@@ -103,6 +103,18 @@ int asr_load_tensor(asr_handle* h, const char* tf_var_name, const float* data,
 /* Fails with ASR_ERR_WEIGHTS (message lists the names) while any graph variable is missing;
  * on success packs the weights into their device layouts. */
 int asr_finalize_weights(asr_handle* h);
+/* Instead of asr_load_tensor + asr_finalize_weights: `h` uses the packed device weights `from` holds (one copy per GPU for
+ * all handles of an asr_amd.model.EnginePool; the weights are read-only once finalized).  The reference's counterpart is
+ * its single graph: every sess.run of evaluate.py:46-47 reads the one set of variables restored at evaluate.py:36.  Both
+ * handles must live on the same GPU with the same model shape and precision mode (else ASR_ERR_ARG); `from` must be
+ * finalized, `h` must not be (ASR_ERR_STATE).  The store is reference-counted: either handle may be destroyed first.
+ * asr_device_bytes counts the store on the handle that filled it only. */
+int asr_share_weights(asr_handle* h, asr_handle* from);
+/* asr_config.shared_gpu / sub_batches for the calls that follow (same value ranges; sub_batches 0 = automatic).  A pool
+ * of handles switches to the shared-GPU regime while it decodes batches side by side and back when one of its handles is
+ * used alone (Model.predict, Evaluator.loss), so that a lone call gets the K-slices, tiles and two-stream halves that
+ * fill the chip by themselves.  Not while another thread is inside a call on `h`.  No counterpart in the reference. */
+int asr_set_sharing(asr_handle* h, int32_t shared_gpu, int32_t sub_batches);
 
 /* Replaces: `Evaluator.beam_search(X)` for one device shard (evaluate.py:46-47; model.py:176-178):
  * X [n, t, d] float32 row-major, all-zero rows are padding (model.py:450).  Y receives int32
@@ -205,15 +217,18 @@ int asr_op_pack_cross_kv(asr_handle* h, const float* kv, int32_t n, int32_t t, i
 int asr_op_input_norm_timing(asr_handle* h, const float* x, const float* gamma, const float* beta,
                              int32_t n, int32_t t, int32_t hidden, float* y);
 /* Allocation-free variant of asr_op_input_norm_timing.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
- * cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc).  The call itself launches on the
+ * handle's private stream and waits for it, so it cannot be recorded into a HIP graph by a caller's stream capture.
  * x_dev / gamma_dev / beta_dev / y_dev are DEVICE pointers on the handle's GPU, 16-byte aligned (x, y [n,t,hidden];
  * gamma, beta [hidden]); the per-utterance partial sums that the other entry point keeps in a hipMalloc'ed buffer live
  * in a static device array of the library (1 MiB per GPU, held until the process ends).  Calls no hipMalloc / hipFree
  * and no allocating routine.  Limits: n <= 1024 utterances per call and t <= the positions of the handle's timing
  * table (max(512, max_target_length + 2), or more once another entry point has grown it); beyond either the call
  * fails with ASR_ERR_CAPACITY and touches nothing.  All calls on one GPU share that GPU's array (the last call's
- * contents are overwritten, nothing needs clearing): calls that OVERLAP on one GPU - two handles of one device used
- * from two threads - race.  Blocks until y_dev is valid.  Results are bit-identical to asr_op_input_norm_timing. */
+ * contents are overwritten, nothing needs clearing): calls on one GPU from several host threads - handles of one device in
+ * an EnginePool - take turns on a per-GPU mutex of the library, held from the launch to the end of the wait; a caller that
+ * launched its own kernels on that array would race.  Blocks until y_dev is valid.  Results are bit-identical to
+ * asr_op_input_norm_timing. */
 int asr_op_input_norm_timing_noalloc(asr_handle* h, const float* x_dev, const float* gamma_dev, const float* beta_dev,
                                      int32_t n, int32_t t, int32_t hidden, float* y_dev);
 /* Decode-time encoder-decoder attention core of one decoder block at one step (model.py:604-616 -> utils.py:612-631,
@@ -266,7 +281,7 @@ int asr_set_profile(asr_handle* h, int32_t mode);
  * bracket; the total subtracted is returned as the last class, named "(event_pair_overhead)". */
 int asr_get_profile(asr_handle* h, int32_t cap, const char** names, double* ms, int64_t* launches,
                     double* flops, double* bytes, int32_t* n_out);
-/* Device-memory footprint of the handle in bytes (weights + caches + workspaces). */
+/* Device-memory footprint of the handle in bytes (caches + workspaces + the weight store if this handle filled it). */
 int64_t asr_device_bytes(const asr_handle* h);
 
 /* ASR_PRECISION_F32_F16X3 only: how many calls on this handle were repeated on the F32_BF16X6 kernels because an operand

