@@ -92,6 +92,7 @@ struct asr_handle {
     int32_t* grp_buf = nullptr;         // device home of those arrays and of the per-utterance loop limits: [3][grp_cap]
     size_t grp_cap = 0;
     int logit_split = 1;                // K slices of the logits GEMM (their slabs are summed by the top-k kernel)
+    int logit_split_shared = 2;         // ... of handles that share the GPU, from 576 beam rows (env ASR_AMD_LOGIT_SPLIT_SHARED: development)
     float* emb_gemm = nullptr;          // logits operand when tied: = emb (f32 mode) or its bf16 planes
     hipStream_t stream = nullptr;
     mutable std::string err;
@@ -568,6 +569,16 @@ int decode_splits(const asr_handle* h, int R, int* s_qkv, int* s_proj, int* s_ff
     return 0;
 }
 
+// K-slices of the logits GEMM for R beam rows (their slabs are summed by the soft-max / top-k kernel): at most two.  Handles that
+// share the GPU run whole-batch row counts unsplit like the other projections (every slab is written and read once more, and
+// the XCD partition of gemm_split.hip already keeps the weight reads to one XCD each); ASR_AMD_LOGIT_SPLIT pins it (development).
+int logit_split_for(const asr_handle* h, int R)
+{
+    if (const char* e = getenv("ASR_AMD_LOGIT_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2) return v; }
+    if (h->shared_gpu && R >= 576) return h->logit_split_shared;
+    return std::min(2, gemm_pick_split_k(R, h->V, h->H, gemm_nprod(h, h->H)));
+}
+
 int ensure_decoder_capacity(asr_handle* h, int n)
 {
     if (n <= h->cap_dec_n) return ASR_OK;
@@ -593,8 +604,7 @@ int ensure_decoder_capacity(asr_handle* h, int n)
     rc |= dev_alloc_t(h, &h->dctx, R * H);
     rc |= dev_alloc_t(h, &h->part, (size_t)ASR_MAX_SPLITK * R * 3 * H);
     rc |= dev_alloc_t(h, &h->dhid, R * (size_t)h->F);
-    h->logit_split = std::min(2, gemm_pick_split_k((int)R, h->V, (int)H, gemm_nprod(h, (int)H)));        // <= 2 slabs of logits
-    if (const char* e = getenv("ASR_AMD_LOGIT_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2) h->logit_split = v; }   // development
+    h->logit_split = logit_split_for(h, (int)R);                                                          // <= 2 slabs of logits
     rc |= dev_alloc_t(h, &h->logits, 2 * R * (size_t)h->V);
     rc |= dev_alloc_t(h, &h->cand_scores, R * (size_t)h->K);
     rc |= dev_alloc_t(h, &h->cand_tokens, R * (size_t)h->K);
@@ -872,7 +882,7 @@ int step_tail(asr_handle* h, const DecView& v, const StepCtx& c)
     hipStream_t s = v.stream;
     const BeamState& st = v.beam;
     const float* wout = h->cfg.tie_embedding_and_softmax ? h->emb_gemm : h->softmax_w;
-    const int s_log = std::min(2, gemm_pick_split_k(R, h->V, H, gemm_nprod(h, H)));                          // <= 2 slabs of logits
+    const int s_log = logit_split_for(h, R);                                                                 // <= 2 slabs of logits
     int rc = gemm(h, v.y0, wout, nullptr, v.logits, R, h->V, H, EPI_PARTIAL, s_log, s);             // model.py:341 (no bias)
     if (rc) return rc;
     {
@@ -1061,7 +1071,7 @@ int decode_core(asr_handle* h, const float* X_dev, int n, int t, int32_t* Y, int
                     float* dst = tr->logits + (size_t)(s - 1) * R * h->V;
                     const size_t cnt = (size_t)R * h->V;
                     HIP_TRY(h, copy_blocking(h, dst, h->logits, cnt * 4, hipMemcpyDeviceToHost));
-                    if (h->logit_split > 1) {                   // second K slice, added in slab order like the top-k kernel does
+                    if (logit_split_for(h, R) > 1) {            // second K slice, added in slab order like the top-k kernel does
                         std::vector<float> slab(cnt);
                         HIP_TRY(h, copy_blocking(h, slab.data(), h->logits + cnt, cnt * 4, hipMemcpyDeviceToHost));
                         for (size_t i = 0; i < cnt; ++i) dst[i] += slab[i];
@@ -1281,6 +1291,7 @@ int asr_create(const asr_config* cfg, asr_handle** out)
     if ((e = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
     h->shared_gpu = cfg->shared_gpu != 0;
     if (const char* tw = getenv("ASR_AMD_DOUBLE")) h->twice = tw;
+    if (const char* ls = getenv("ASR_AMD_LOGIT_SPLIT_SHARED")) { const int v = atoi(ls); if (v == 1 || v == 2) h->logit_split_shared = v; }
     if (cfg->sub_batches) h->sub_batches = cfg->sub_batches;
     else if (const char* sb = getenv("ASR_AMD_SUBBATCH")) h->sub_batches = std::max(0, std::min(MAX_VIEWS, atoi(sb)));
     if (const char* gr = getenv("ASR_AMD_GRAPH")) h->use_graph = atoi(gr) != 0 ? 1 : 0;

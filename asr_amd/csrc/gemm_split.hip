@@ -38,6 +38,7 @@
 #include "asr_common.h"
 #include "gemm_epilogue.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <atomic>
@@ -73,8 +74,18 @@ __device__ __forceinline__ f32x16 mma32(const u32x4& a, const u32x4& b, const f3
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// Which tiles an XCD works on.  Workgroups are dealt round-robin over the 8 XCDs (workgroup b runs on XCD b % 8: observed,
+// used for speed only), every XCD has an L2 of its own, and whatever two XCDs both read crosses the fabric twice.  The
+// decode-row GEMMs are bound by exactly that traffic when several engine handles share the GPU (tools/corun_bench.hip: a
+// plain streaming read beside the GLU GEMM slows BOTH - memory-side bandwidth, not CU residency), so for few row tiles the
+// XCDs partition the problem as a pz x pm x pn grid (pz pm pn = 8): XCD (xz, xm, xn) owns the K-slices z = xz (mod pz), the
+// xm-th of pm contiguous blocks of row tiles and the xn-th of pn contiguous blocks of column tiles, M-tile fastest.
+// Memory-side reads per launch are then pn A + pm W (A = the activations, W = the weight planes) instead of up to 8 A + 2 W.
+// pz = 0: the legacy order (each XCD a contiguous run of tiles, groups of 8 row tiles: the encoder's 334 row tiles).
+struct TileMap { int pz, pm, pn; };
+
 template <int MI, int NI, int NW, int EPI, int NPROD>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4 ? 3 : 2))) void gemm_split_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4 ? 3 : 2))) void gemm_split_nt_kernel(GemmArgs p, int nt_m, int nt_n, int kchunk, TileMap map)
 {
     static_assert(NW == 4 || NW == 8, "4 or 8 waves side by side");
     constexpr int FPT = 2048 / (NW * 64);              // floats of a 64 x 32 A pass per thread: 8 (4 waves) or 4 (8 waves)
@@ -92,20 +103,34 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // XCD-aware tile order (same as gemm_f32.hip): each XCD gets a contiguous run of tiles, M-tile fastest
-    const int total = nt_m * nt_n;
-    const int bid = blockIdx.x;
-    const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
-    const int tlin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    constexpr int GM = 8;
-    const int group = tlin / (GM * nt_n);
-    const int first_m = group * GM;
-    const int gsz = min(nt_m - first_m, GM);
-    const int bm = first_m + (tlin % gsz);
-    const int bn = (tlin % (GM * nt_n)) / gsz;
+    int bm, bn, z;
+    if (map.pz == 0) {
+        // XCD-aware tile order (same as gemm_f32.hip): each XCD gets a contiguous run of tiles, M-tile fastest
+        const int total = nt_m * nt_n;
+        const int bid = blockIdx.x;
+        const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
+        const int tlin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        constexpr int GM = 8;
+        const int group = tlin / (GM * nt_n);
+        const int first_m = group * GM;
+        const int gsz = min(nt_m - first_m, GM);
+        bm = first_m + (tlin % gsz);
+        bn = (tlin % (GM * nt_n)) / gsz;
+        z = blockIdx.y;
+    } else {
+        const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;          // li-th workgroup dealt to this XCD
+        const int xz = xcd % map.pz, xmn = xcd / map.pz, xm = xmn % map.pm, xn = xmn / map.pm;
+        const int m_lo = xm * nt_m / map.pm, nm = (xm + 1) * nt_m / map.pm - m_lo;
+        const int n_lo = xn * nt_n / map.pn, nn = (xn + 1) * nt_n / map.pn - n_lo;
+        const int nz = max(p.split_k, 1) / map.pz;                      // K-slices per XCD (this launch is 1-D: every XCD pads to the largest share)
+        if (li >= nm * nn * nz) return;                                 // (the grid is padded to the largest XCD's share)
+        bm = m_lo + li % nm;
+        const int rest = li / nm;
+        bn = n_lo + rest % nn;
+        z = xz + map.pz * (rest / nn);
+    }
     const int m0 = bm * BM, n0 = bn * BN;
 
-    const int z = blockIdx.y;
     const int kbeg = z * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
     const int nk = (kend - kbeg) / SBK;                // K % 32 == 0 (checked by the launcher)
@@ -389,7 +414,30 @@ hipError_t launch_split_tile(const GemmArgs& a, hipStream_t s)
         if (e != hipSuccess) return e;
         attr_done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(nt_m * nt_n, split, 1), dim3(NW * 64), lds, s, a, nt_m, nt_n, kchunk);
+    // Few row tiles (the decode rows): partition the tiles over the XCDs so that as little as possible is read by more
+    // than one of them.  Memory-side reads = pn A + pm W; the partition must leave no XCD more than a third above its
+    // even share of workgroups.
+    TileMap map{0, 0, 0};
+    int per_xcd = 0;
+    static const int forced = getenv("ASR_AMD_XCD_MAP") ? atoi(getenv("ASR_AMD_XCD_MAP")) : -1;     // development: 0 = legacy order everywhere
+    if (nt_m <= 32 && forced != 0) {
+        const double A = 4.0 * a.M * a.K, W = 2.0 * NPL * (double)a.N * a.K;
+        const int total = nt_m * nt_n * split;
+        double best = 0.0;
+        for (int pz = 1; pz <= 8; pz *= 2) {
+            if (split % pz) continue;
+            for (int pm = 1; pm * pz <= 8; pm *= 2) {
+                const int pn = 8 / (pm * pz);
+                if (pm > nt_m || pn > nt_n) continue;
+                const int share = ((nt_m + pm - 1) / pm) * ((nt_n + pn - 1) / pn) * (split / pz);
+                if (share * 8 > total + total / 3 + 8) continue;
+                const double traffic = pn * A + pm * W;
+                if (!per_xcd || traffic < best) { best = traffic; map = TileMap{pz, pm, pn}; per_xcd = share; }
+            }
+        }
+    }
+    if (per_xcd) hipLaunchKernelGGL(kern, dim3(8 * per_xcd, 1, 1), dim3(NW * 64), lds, s, a, nt_m, nt_n, kchunk, map);
+    else hipLaunchKernelGGL(kern, dim3(nt_m * nt_n, split, 1), dim3(NW * 64), lds, s, a, nt_m, nt_n, kchunk, map);
     return hipGetLastError();
 }
 

@@ -26,6 +26,9 @@ from .utils import shard_bounds
 # kernels (`f32_bf16x6`: three bf16 terms, six products, no range limit); `precision: f32` selects the exact-f32 matrix
 # instructions (include/asr_amd.h asr_precision).
 DEFAULT_PRECISION = 'f32_f16x3'
+# beam rows from which a handle that shares the GPU picks its K-slices independently of the row count (engine.hip decode_splits,
+# logit_split_for): batches of at least that many rows can be decoded in pairs with bit-identical hypotheses
+PAIR_MIN_ROWS = 576
 
 
 def asr_config_from(config, device=0):
@@ -531,7 +534,39 @@ class Model(object):
                 done = (call(self.engines[0], Xs) for Xs in jobs())
             return (Y for Ys in done for Y in Ys)
         if self._num_towers == 1 and len(self.pools) == 1 and len(self.pools[0].engines) > 1:
-            return self.pools[0].map(lambda e, X: e.decode(np.asarray(X, dtype=np.float32)), batches)
+            pair = self._config.test.pair_batches if self._config.test else None
+            if pair is None:
+                pair = os.environ.get('ASR_AMD_PAIR_BATCHES', '1') != '0'
+            if not pair:
+                return self.pools[0].map(lambda e, X: e.decode(np.asarray(X, dtype=np.float32)), batches)
+            # Whole batches (576 beam rows or more each) are decoded two per library call (Engine.decode_groups): every weight
+            # plane is streamed once for both.  From that row count on the handles of a pool choose the same K-slices whatever the
+            # number of rows, so every float32 sum is taken in the same order as in a call of the batch alone: the SAME hypotheses,
+            # bit for bit (`test.pair_batches: false` / ASR_AMD_PAIR_BATCHES=0 turns it off).  Smaller batches go one per call.
+            beam = int(self._config.test.beam_size)
+
+            def paired():
+                held = None
+                for X in batches:
+                    X = np.asarray(X, dtype=np.float32)
+                    whole = X.shape[0] * beam >= PAIR_MIN_ROWS
+                    if held is not None:
+                        if whole:
+                            yield [held, X]
+                            held = None
+                            continue
+                        yield [held]
+                        held = None
+                    if whole:
+                        held = X
+                    else:
+                        yield [X]
+                if held is not None:
+                    yield [held]
+
+            def call(e, Xs):
+                return [e.decode(Xs[0])] if len(Xs) == 1 else e.decode_groups(Xs)
+            return (Y for Ys in self.pools[0].map(call, paired()) for Y in Ys)
         return (self.predict(X) for X in batches)
 
     def predict(self, X):

@@ -19,7 +19,10 @@ child joins a gloo group, the ranks are all-gathered, rank 0 prints {"dry_launch
 A step = one 64-utterance batch through the whole path.  By default FOUR steps are in flight on every GPU
 (`--in-flight 4`: four engine handles, asr_amd.model.EnginePool, each decoding whole steps one after the other): the
 K timed steps are the same K batches decoded the same way, `ms_per_step` = elapsed / K; the line also carries
-`one_step_at_a_time` (the same measurement with `--in-flight 1`).
+`one_step_at_a_time` (the same measurement with `--in-flight 1`).  A handle decodes TWO steps per library call
+(`--steps-per-decode 2`, what `Model.predict_batches` does by default with whole batches queued: every weight plane is
+streamed once for both batches; each batch keeps its own hypotheses, bit for bit); `one_step_per_decode` is the same
+measurement with every 64-utterance batch a call of its own.
 
 The same line also carries, at N = 1 (all timed by this run, on this box):
   roofline            dominant kernel class, HIP events around every launch of one extra pass that launches the same
@@ -361,9 +364,13 @@ def parse_args(argv=None):
     ap.add_argument('--alt-steps', type=int, default=8)
     ap.add_argument('--in-flight', type=int, default=4, help='steps (whole batches) being decoded at any time on one GPU, each by an '
                     'engine handle of its own (asr_amd.model.EnginePool); 1 = one step at a time')
+    ap.add_argument('--steps-per-decode', type=int, default=2, choices=[1, 2], help='steps (64-utterance batches) a handle decodes per library '
+                    'call: 2 = what Model.predict_batches does by default with whole batches queued (pairs of batches as one joint decode of '
+                    '1280-row kernels: every weight plane is streamed once for both; every batch keeps its own padding, loop limit and '
+                    'hypotheses), 1 = one batch per call')
     ap.add_argument('--precision', default=os.environ.get('ASR_AMD_PRECISION', 'f32_f16x3'), choices=sorted(PRECISION_INFO))
     ap.add_argument('--workload', default='fixed', choices=['fixed', 'bucketed'])
-    ap.add_argument('--no-two-steps', action='store_true', help='skip the two-steps-per-decode leg (--no-one-at-a-time skips it as well)')
+    ap.add_argument('--no-two-steps', action='store_true', help='skip the one-step-per-decode leg (--no-one-at-a-time skips it as well)')
     ap.add_argument('--merge-utts', type=int, default=0, help='--workload bucketed: join a rank\'s batches into joint decodes of up to this '
                     'many utterances (Engine.decode_groups); 0 = batch by batch like the reference\'s translate loop')
     ap.add_argument('--utts-per-gpu', type=int, default=512, help='--workload bucketed: utterances per GPU (a test set of a few hundred utterances fills the 10-frame buckets; 64 leaves mostly single-utterance batches)')
@@ -592,33 +599,44 @@ def main():
     eng = pool.engines[0]
 
     n, t_raw = args.batch, args.t_raw
+    spd = args.steps_per_decode
     raw = synthetic_raw(n, t_raw, seed=1000 + rank)
-    d_raw = torch.from_numpy(raw).cuda(local_rank)
+    # the second batch of a pair is another batch (other utterances): nothing is shared between the two but the kernels
+    raw_pair = np.concatenate([raw, synthetic_raw(n, t_raw, seed=2000 + rank)]) if spd == 2 else raw
+    d_raw = torch.from_numpy(raw_pair).cuda(local_rank)
     torch.cuda.synchronize()
     width = args.max_target_length + 1
     front = (t_raw, 80, 3, 0, 3)
     seen_ranks = [[0]]
 
-    def decode(e, _=None):
+    def decode(e, _=None):                                   # one step: the first batch alone
         return e.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
+
+    def decode_call(e, nsteps):                              # nsteps (1 or 2) steps in one library call -> their hypotheses, step by step
+        Y = e.decode_dev(d_raw.data_ptr(), nsteps * n, 0, 0, raw=front)
+        return [Y[i * n:(i + 1) * n] for i in range(nsteps)]
 
     def gather(Y):          # the hypotheses of a step (fixed width, padded with 3; column 0 = the rank) on every rank: the path's only exchange
         if world > 1:
             buf = torch.full((n, width + 1), 3, dtype=torch.int32)
             buf[:, 0] = rank
-            buf[:, 1:1 + Y.shape[1]] = torch.from_numpy(Y)
+            buf[:, 1:1 + Y.shape[1]] = torch.from_numpy(np.ascontiguousarray(Y))
             if not rehearse:
                 buf = buf.cuda(local_rank)
             out = [torch.empty_like(buf) for _ in range(world)]
             dist.all_gather(out, buf)
             seen_ranks[0] = sorted(set(int(o[0, 0].item()) for o in out))
 
-    def run_steps(p, k):
-        """k steps through pool p: results come back in step order on this thread, which gathers each while the
-        pool's threads go on decoding the next ones."""
+    def run_steps(p, k, per_call=None):
+        """k steps through pool p, `per_call` of them per library call: results come back in step order on this thread, which
+        gathers each step's hypotheses while the pool's threads go on decoding the next ones.  Returns the FIRST batch's Y."""
+        per_call = per_call or spd
+        calls = [per_call] * (k // per_call) + ([k % per_call] if k % per_call else [])
         Y = None
-        for Y in p.map(decode, range(k)):
-            gather(Y)
+        for Ys in p.map(decode_call, calls):
+            for Yi in Ys:
+                gather(Yi)
+            Y = Ys[0]
         return Y
 
     def fence():
@@ -627,15 +645,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(p, k):
+    def timed(p, k, per_call=None):
         fence()
         t0 = time.perf_counter()
-        Y = run_steps(p, k)
+        Y = run_steps(p, k, per_call)
         fence()
         return time.perf_counter() - t0, Y
 
-    # W untimed steps - and at least one on every handle, so that no handle's first call falls into the timed region
-    Y = run_steps(pool, max(args.warmup, len(pool.engines)) if args.warmup > 0 else 0)
+    # W untimed steps - and at least one call on every handle, so that no handle's first call falls into the timed region
+    Y = run_steps(pool, max(args.warmup, spd * len(pool.engines)) if args.warmup > 0 else 0)
     elapsed, Y = timed(pool, args.steps)
     per_rank = [elapsed]
     if world > 1:
@@ -659,11 +677,13 @@ def main():
                                    % ('char config' if args.vocab == 3900 else 'char architecture with another vocabulary',
                                       args.vocab, args.beam, args.max_target_length, n, t_raw / 100.0, (t_raw + 2) // 3,
                                       Y.shape[1],
-                                      ('%d steps in flight per GPU: %d engine handles, each decoding whole steps one after the '
-                                       'other as one run of %d-row kernels; ms_per_step = elapsed / steps' % (nfl, nfl, n * args.beam))
+                                      ('%d steps in flight per GPU: %d engine handles, each decoding %s as one run of %d-row kernels; '
+                                       'ms_per_step = elapsed / steps'
+                                       % (nfl * spd, nfl, 'whole steps one after the other' if spd == 1 else
+                                          'two steps (two 64-utterance batches) per call', spd * n * args.beam))
                                       if nfl > 1 else 'one step at a time'),
                        'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world, 'precision': args.precision,
-                       'steps_in_flight': nfl, 'hw_queues': HWQ['value'], 'hw_queues_source': HWQ['source'],
+                       'steps_in_flight': nfl * spd, 'engine_handles': nfl, 'steps_per_decode': spd, 'hw_queues': HWQ['value'], 'hw_queues_source': HWQ['source'],
                        # precision f32_f16x3: calls the library repeated on the bf16x6 kernels because an operand left
                        # fp16's range (0 = every timed step ran on the fp16x3 kernels)
                        'range_retries': sum(e.range_retries() for e in pool.engines),
@@ -680,15 +700,15 @@ def main():
         import threading
         with pool.together():                     # the regime of the timed region (EnginePool.map enters it by itself)
             eng.set_profile(2)
-            others = [threading.Thread(target=lambda e=e: [decode(e) for _ in range(2)]) for e in pool.engines[1:]]
+            others = [threading.Thread(target=lambda e=e: [decode_call(e, spd) for _ in range(2)]) for e in pool.engines[1:]]
             for th in others:
                 th.start()
-            decode(eng)
+            decode_call(eng, spd)                 # the call of the timed region: `spd` steps as one run of kernels
             prof = eng.get_profile()
             for th in others:
                 th.join()
             eng.set_profile(1)
-            decode(eng)
+            decode_call(eng, spd)
             solo = {p['name']: p for p in eng.get_profile()}
             eng.set_profile(0)
         out['roofline'], out['kernels'] = roofline_of(prof, args.precision)
@@ -699,7 +719,8 @@ def main():
         # `achieved` / `frac` are per launch AS TIMED, i.e. with the other handle's kernels sharing the GPU (a kernel then
         # has about half the chip); the same class alone on the GPU:
         rf = out['roofline']
-        rf['steps_in_flight'] = nfl
+        rf['steps_in_flight'] = nfl * spd
+        rf['steps_per_launch'] = spd               # a launch of the profiled call serves `spd` steps (64-utterance batches)
         p1 = solo.get(rf['kernel'])
         if p1 and p1['ms'] > 0:
             rf['solo_avg_us'] = 1000.0 * p1['ms'] / p1['launches']
@@ -709,11 +730,11 @@ def main():
         # kernel gets of it.  executed = algorithmic x the 16-bit products per multiply of the dense layers' kernels.
         nprod_mode = PRECISION_INFO[args.precision][1]
         step_s = 1e-3 * out['ms_per_step']                  # per GPU: every rank decodes a batch of its own per step
-        alg = sum(p['flops'] for p in prof if not p['name'].startswith('('))
-        exe = sum(p['flops'] * (nprod_mode if p['name'].startswith('gemm') else 1) for p in prof if not p['name'].startswith('('))
+        alg = sum(p['flops'] for p in prof if not p['name'].startswith('(')) / spd          # (the profiled call decoded `spd` steps)
+        exe = sum(p['flops'] * (nprod_mode if p['name'].startswith('gemm') else 1) for p in prof if not p['name'].startswith('(')) / spd
         ws = {'algorithmic_tflop': alg / 1e12, 'algorithmic_tflops': alg / step_s / 1e12,
               'executed_tflops': exe / step_s / 1e12, 'executed_frac_of_mfma_peak': exe / step_s / 1e12 / PRECISION_INFO[args.precision][2],
-              'algorithmic_gb': sum(p['bytes'] for p in prof if not p['name'].startswith('(')) / 1e9}
+              'algorithmic_gb': sum(p['bytes'] for p in prof if not p['name'].startswith('(')) / spd / 1e9}
         ws['algorithmic_gbs'] = ws['algorithmic_gb'] / step_s
         ws['algorithmic_frac_of_hbm_peak'] = ws['algorithmic_gbs'] / PEAK_HBM_GBS
         tr = [(measured_traffic(p['name'], args.precision) or measured_traffic(p['name'] + '_reg', args.precision), p['launches'])
@@ -721,7 +742,7 @@ def main():
         if all(t is not None for t, _ in tr):
             # memory-side traffic (PMC FETCH_SIZE / WRITE_SIZE per launch, profiles/): reads that missed the L2s, served by
             # the Infinity Cache or by HBM
-            ws['pmc_traffic_gb'] = sum(t * l for t, l in tr) / 1e9
+            ws['pmc_traffic_gb'] = sum(t * l for t, l in tr) / spd / 1e9
             ws['pmc_traffic_gbs'] = ws['pmc_traffic_gb'] / step_s
             ws['pmc_traffic_frac_of_hbm_peak'] = ws['pmc_traffic_gbs'] / PEAK_HBM_GBS
         rf['whole_step'] = {k: round(v, 4) for k, v in ws.items()}
@@ -738,41 +759,27 @@ def main():
             # the same steps one at a time (one handle, the library's default: two half batches on two streams)
             p1 = EnginePool(cfg, local_rank, 1)
             p1.load_weights(W)
-            run_steps(p1, 1)
-            dt, Y1 = timed(p1, args.alt_steps)
+            run_steps(p1, 1, 1)
+            dt, Y1 = timed(p1, args.alt_steps, 1)
             m = min(Y1.shape[1], Y.shape[1])
             same = np.all(Y1[:, :m] == Y[:, :m], axis=1)
             out['one_step_at_a_time'] = {'value': n * t_raw / 100.0 * args.alt_steps / dt, 'unit': 'audio-sec/sec',
                                          'ms_per_step': 1000.0 * dt / max(args.alt_steps, 1), 'steps': args.alt_steps,
                                          'utterances_identical': '%d of %d' % (int(same.sum()), n)}
             p1.close()
-        if world == 1 and nfl > 1 and not (args.no_two_steps or args.no_one_at_a_time):
-            # two steps per decode call: every handle decodes TWO 64-utterance batches as one run of kernels (what
-            # Engine.decode_groups does with the bucketed reader's batches; here both have the same padded length, so the call
-            # is a 128-utterance decode).  Reported beside the headline, never as `value`.
+        if world == 1 and nfl > 1 and spd > 1 and not (args.no_two_steps or args.no_one_at_a_time):
+            # one step per library call on every handle (round 2's headline setting): the same steps, every 64-utterance
+            # batch a call of its own
             p2 = EnginePool(cfg, local_rank, nfl)
             p2.load_weights(W)
-            raw2 = np.concatenate([raw, synthetic_raw(n, t_raw, seed=2000 + rank)])
-            d_raw2 = torch.from_numpy(raw2).cuda(local_rank)
-
-            def decode2(e, _=None):
-                return e.decode_dev(d_raw2.data_ptr(), 2 * n, 0, 0, raw=front)
-            for _ in p2.map(decode2, range(nfl)):
-                pass
-            k2 = max(nfl, args.alt_steps // 2)
-            fence()
-            t0 = time.perf_counter()
-            for Y2 in p2.map(decode2, range(k2)):
-                pass
-            fence()
-            dt = time.perf_counter() - t0
+            run_steps(p2, nfl, 1)
+            dt, Y2 = timed(p2, args.alt_steps, 1)
             m = min(Y2.shape[1], Y.shape[1])
-            same = np.all(Y2[:n, :m] == Y[:, :m], axis=1)
-            out['two_steps_per_decode'] = {'value': 2 * n * t_raw / 100.0 * k2 / dt, 'unit': 'audio-sec/sec',
-                                           'ms_per_step': 1000.0 * dt / (2 * k2), 'steps': 2 * k2, 'decodes_in_flight': nfl,
-                                           'utterances_identical': '%d of %d' % (int(same.sum()), n)}
+            same = np.all(Y2[:, :m] == Y[:, :m], axis=1)
+            out['one_step_per_decode'] = {'value': n * t_raw / 100.0 * args.alt_steps / dt, 'unit': 'audio-sec/sec',
+                                          'ms_per_step': 1000.0 * dt / max(args.alt_steps, 1), 'steps': args.alt_steps, 'engine_handles': nfl,
+                                          'utterances_identical': '%d of %d' % (int(same.sum()), n)}
             p2.close()
-            del d_raw2
         if world == 1 and not args.no_alt_precisions:
             # the other dense-layer arithmetics on the same batch, timed by this same run the same way (fresh handles;
             # the headline's are closed first)

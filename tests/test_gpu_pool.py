@@ -179,3 +179,38 @@ def test_evaluate_as_one_process_per_gpu_writes_the_single_process_file(tmp_path
             lines.append('spk%02d-utt%d' % (i % 2, i) + '\t' + sent)
     want = ''.join(re.sub(r'(@@ )|(@@ ?$)', '', ln) + '\n' for ln in lines)
     assert got.decode('utf-8') == want
+
+
+def test_whole_batches_are_decoded_in_pairs_with_bit_identical_hypotheses():
+    """Model.predict_batches with several handles: consecutive batches of at least 576 beam rows go two per library call
+    (Engine.decode_groups; one pass over every weight plane for both).  From that row count on a pool's handles pick their
+    K-slices independently of the number of rows, so the pair must reproduce the one-batch-per-call hypotheses BIT for bit:
+    full-size char architecture, batches of 64 / 60 / 64 / 20 utterances with different padded lengths, beam 10, and the
+    float32 oracle's hypotheses for every batch."""
+    from asr_amd.model import Model
+    ocfg = O.make_config(beam_size=10, max_target_length=4)
+    W = O.random_weights(ocfg, seed=51)
+    shapes = [(64, 90), (60, 120), (64, 75), (20, 60)]
+    Xs = [O.make_batch(O.synthetic_fbank(n, [top - 3 * (i % 5) for i in range(n)], seed=300 + j)) for j, (n, top) in enumerate(shapes)]
+    want = [O.build_test_model(X, W, ocfg, num_gpus=1, algo='kv') for X in Xs]
+    got = {}
+    for pair in (True, False):
+        cfg = product_config(ocfg)
+        cfg.test['engines_per_gpu'] = 2
+        cfg.test['pair_batches'] = pair
+        m = Model(cfg, 1, devices=[0])
+        m.build_test_model()
+        m.restore(W)
+        calls = []
+        for e in m.pools[0].engines:
+            dg, dc = e.decode_groups, e.decode
+            e.decode_groups = lambda Xg, dg=dg: (calls.append([X.shape[0] for X in Xg]), dg(Xg))[1]
+            e.decode = lambda X, dc=dc: (calls.append([X.shape[0]]), dc(X))[1]
+        try:
+            got[pair] = list(m.predict_batches(iter(Xs)))
+        finally:
+            m.close()
+        assert sorted(calls) == ([[20], [64], [64, 60]] if pair else [[20], [60], [64], [64]])
+    for Yp, Y1, Yw in zip(got[True], got[False], want):
+        assert Yp.shape == Y1.shape and np.array_equal(Yp, Y1)          # paired == alone, bit for bit
+        assert np.array_equal(Y1, Yw)                                    # == the oracle's

@@ -359,3 +359,44 @@ def test_model_defaults_to_the_measured_handle_count(monkeypatch):
     assert Model(product_config(ocfg), 1)._engines_per_gpu == 1
     monkeypatch.delenv('ASR_AMD_ENGINES')
     assert Model(product_config(ocfg, num_gpus=3), 3)._engines_per_gpu == 1
+
+
+def test_predict_batches_pairs_whole_batches_and_keeps_their_order():
+    """Without `test.merge_utts`, a pool of several handles decodes consecutive WHOLE batches (>= 576 beam rows each) two per
+    call and everything else one per call; results come back batch by batch in order; `test.pair_batches: false` turns it off."""
+    from asr_amd.model import EnginePool, Model
+    calls = []
+
+    class Fake(object):
+        _h = 1
+
+        def decode(self, X):
+            calls.append([X.shape[0]])
+            return np.full((X.shape[0], 2), X.shape[1], np.int32)
+
+        def decode_groups(self, Xs):
+            calls.append([X.shape[0] for X in Xs])
+            return [np.full((X.shape[0], 2), X.shape[1], np.int32) for X in Xs]
+
+        def set_sharing(self, *a):
+            pass
+
+    def batches():
+        for n, t in [(64, 10), (64, 11), (64, 12), (5, 13), (64, 14), (60, 15), (57, 16), (64, 17)]:
+            yield np.zeros((n, t, 4), np.float32)
+    for pair in (None, False):
+        cfg = product_config(tiny_config(beam_size=10))
+        if pair is not None:
+            cfg.test['pair_batches'] = pair
+        m = Model(cfg, 1, devices=[0])
+        pool = object.__new__(EnginePool)
+        pool.engines = [Fake(), Fake()]
+        m.pools, m.engines = [pool], [pool.engines[0]]
+        calls[:] = []
+        out = list(m.predict_batches(batches()))
+        assert [int(y[0, 0]) for y in out] == [10, 11, 12, 13, 14, 15, 16, 17]
+        assert [y.shape[0] for y in out] == [64, 64, 64, 5, 64, 60, 57, 64]
+        if pair is None:
+            assert sorted(calls) == sorted([[64, 64], [64], [5], [64, 60], [57], [64]])
+        else:
+            assert sorted(calls) == sorted([[64], [64], [64], [5], [64], [60], [57], [64]])
