@@ -344,6 +344,17 @@ def run_bucketed(args, rank, local_rank, world, rehearse, W=None):
     return out
 
 
+def plan_calls(k, handles, per_call):
+    """k steps as library calls of at most `per_call` steps for a pool of `handles`: every handle gets the same number of steps
+    (+- 1), in calls as large as allowed, the large calls first - so that the last round of a finite run does not leave
+    handles idle while one of them still decodes a pair (a stream of batches without end has no such tail)."""
+    per_handle = [k // handles + (1 if i < k % handles else 0) for i in range(handles)]
+    calls = []
+    for steps in per_handle:
+        calls += [per_call] * (steps // per_call) + ([steps % per_call] if steps % per_call else [])
+    return sorted(calls, reverse=True)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1, help='ranks = GPUs of this node.  Without a launcher (no RANK in the environment) and N > 1 '
@@ -364,7 +375,7 @@ def parse_args(argv=None):
     ap.add_argument('--alt-steps', type=int, default=8)
     ap.add_argument('--in-flight', type=int, default=4, help='steps (whole batches) being decoded at any time on one GPU, each by an '
                     'engine handle of its own (asr_amd.model.EnginePool); 1 = one step at a time')
-    ap.add_argument('--steps-per-decode', type=int, default=2, choices=[1, 2], help='steps (64-utterance batches) a handle decodes per library '
+    ap.add_argument('--steps-per-decode', type=int, default=2, choices=[1, 2, 3, 4], help='steps (64-utterance batches) a handle decodes per library '
                     'call: 2 = what Model.predict_batches does by default with whole batches queued (pairs of batches as one joint decode of '
                     '1280-row kernels: every weight plane is streamed once for both; every batch keeps its own padding, loop limit and '
                     'hypotheses), 1 = one batch per call')
@@ -602,7 +613,7 @@ def main():
     spd = args.steps_per_decode
     raw = synthetic_raw(n, t_raw, seed=1000 + rank)
     # the second batch of a pair is another batch (other utterances): nothing is shared between the two but the kernels
-    raw_pair = np.concatenate([raw, synthetic_raw(n, t_raw, seed=2000 + rank)]) if spd == 2 else raw
+    raw_pair = np.concatenate([raw] + [synthetic_raw(n, t_raw, seed=2000 * i + rank) for i in range(1, spd)]) if spd > 1 else raw
     d_raw = torch.from_numpy(raw_pair).cuda(local_rank)
     torch.cuda.synchronize()
     width = args.max_target_length + 1
@@ -631,7 +642,7 @@ def main():
         """k steps through pool p, `per_call` of them per library call: results come back in step order on this thread, which
         gathers each step's hypotheses while the pool's threads go on decoding the next ones.  Returns the FIRST batch's Y."""
         per_call = per_call or spd
-        calls = [per_call] * (k // per_call) + ([k % per_call] if k % per_call else [])
+        calls = plan_calls(k, len(p.engines), per_call)
         Y = None
         for Ys in p.map(decode_call, calls):
             for Yi in Ys:
@@ -680,7 +691,7 @@ def main():
                                       ('%d steps in flight per GPU: %d engine handles, each decoding %s as one run of %d-row kernels; '
                                        'ms_per_step = elapsed / steps'
                                        % (nfl * spd, nfl, 'whole steps one after the other' if spd == 1 else
-                                          'two steps (two 64-utterance batches) per call', spd * n * args.beam))
+                                          '%d steps (%d 64-utterance batches) per call' % (spd, spd), spd * n * args.beam))
                                       if nfl > 1 else 'one step at a time'),
                        'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world, 'precision': args.precision,
                        'steps_in_flight': nfl * spd, 'engine_handles': nfl, 'steps_per_decode': spd, 'hw_queues': HWQ['value'], 'hw_queues_source': HWQ['source'],

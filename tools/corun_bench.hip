@@ -35,6 +35,36 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const f32x4* __restric
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[blockIdx.x] = acc[0];
 }
 
+// nothing but matrix instructions on register operands (random, non-zero: the power of a real GEMM's inner loop without any
+// of its memory traffic): `iters` x 8 v_mfma_f32_32x32x16_f16 per wave, 8 waves per workgroup
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512) void mfma_only_kernel(const float* __restrict__ seed, int iters, float* __restrict__ out)
+{
+    f16x8_t a[4], b[2];
+    const float s0 = seed ? seed[threadIdx.x & 255] : 0.0f;      // null: all-zero operands (same instruction stream, far less switching power)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[i][j] = (_Float16)(s0 * (float)(i + 1) + (seed ? 0.01f * (float)j : 0.0f));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[i][j] = (_Float16)(s0 * 0.5f - (seed ? 0.02f * (float)(i + j) : 0.0f));
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[i >> 2], acc[i], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][7];
+    if (t == 12345.678f) out[blockIdx.x] = t;
+}
+
 __global__ void empty_kernel(float* out) { if (out == nullptr) out[0] = 0.f; }
 
 struct Timed { float ms_a = 0.f, ms_b = 0.f, ms_all = 0.f; };
@@ -133,7 +163,13 @@ int main(int argc, char** argv)
         }
         return hipGetLastError();
     };
+    const bool mfma_only = !strcmp(gname, "mfma");            // the GEMM's side replaced by bare matrix instructions (no memory traffic)
     auto launch_b = [&](int i) -> hipError_t {
+        if (mfma_only) {
+            // as many matrix instructions as the GLU GEMM executes: 3 x 2 x 640 x 8192 x 1024 flop / (2 x 32 x 32 x 16 per MFMA) over 2048 waves
+            hipLaunchKernelGGL(mfma_only_kernel, dim3(256), dim3(512), 0, sb, hot_w ? static_cast<const float*>(nullptr) : q, 60, sink);
+            return hipGetLastError();
+        }
         ga.Wp = reinterpret_cast<const uint16_t*>(Wp + (size_t)(i % copies) * wbytes);
         return launch_gemm_split(ga, nprod, tile, sb);
     };
