@@ -3,7 +3,7 @@
 # (ASR_AMD_DOUBLE, include/asr_amd.h has no part in it: a measurement aid of the engine).  Usage (GPU box):
 #   tools/marginal_cost.sh [in-flight, default 4] > gpurun_out/marginal_cost.txt
 IF=${1:-4}
-X="--no-cpu-baseline --no-alt-precisions --no-one-at-a-time --steps 12 --in-flight $IF"
+X="--no-cpu-baseline --no-alt-precisions --no-one-at-a-time --no-configs --steps 16 --in-flight $IF"
 for c in none glu proj qkv ffn2 logits self cross ln topk encoder none; do
     ASR_AMD_DOUBLE=$c timeout -k 10 250 python bench.py $X > /tmp/mc.json 2>/dev/null || exit 1
     python -c "
