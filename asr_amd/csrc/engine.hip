@@ -306,6 +306,8 @@ inline bool pack_planes(const asr_handle* h, const float* w, int n, int k, uint1
 // with other handles' kernels in the queue there are no idle rounds to avoid (four steps in flight, same box: 203.0 -> 201.7 ms).
 inline int split_tile_for(const asr_handle* h, int M, int N, int K, int split_k, int epilogue)
 {
+    static const int forced = getenv("ASR_AMD_DECODE_TILE") ? atoi(getenv("ASR_AMD_DECODE_TILE")) : 0;   // development: 2, 6 or 9 for the decode rows
+    if (forced && M <= 4096) return forced;
     const int t = gemm_split_pick_tile(M, N, K, split_k, epilogue);
     return (t == 6 && h->shared_gpu) ? 9 : t;
 }

@@ -50,6 +50,15 @@ namespace {
 
 constexpr int SBK = 32;   // k-depth of one LDS stage
 
+// Weight fragment loads.  ASR_GEMM_W_NT (development build): non-temporal, meant to keep the weight stream from displacing the
+// activations in the XCD's L2.  Measured, same-box A/B of the whole bench (round 3): 185.3 -> 229.0 ms per step - the row tiles of
+// a column tile share their weight panel THROUGH the L2, and non-temporal lines do not stay long enough for that.  Not used.
+#ifdef ASR_GEMM_W_NT
+#define W_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define W_LOAD(p) (*(p))
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int n = 0; n < NI; ++n) {
-                const u32x4 v = wfrag[n][off + pl * 128];
+                const u32x4 v = W_LOAD(&wfrag[n][off + pl * 128]);
                 if (ks == 0) rw[S][0][pl][n] = v; else rw[S][1][pl][n] = v;
             }
     };
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int n = 0; n < NI; ++n)
-                if (op == pl * NI + n) rw[S][KS][pl][n] = wfrag[n][g_woff + KS * 64 + pl * 128];
+                if (op == pl * NI + n) rw[S][KS][pl][n] = W_LOAD(&wfrag[n][g_woff + KS * 64 + pl * 128]);
     };
     // the MFMAs of k-step KS of the tile in W set WS, A fragments from slot FS; side ops [n NOPS / NM, (n + 1) NOPS / NM)
     // follow the n-th MFMA
@@ -431,6 +440,9 @@ hipError_t launch_split_tile(const GemmArgs& a, hipStream_t s)
                 if (pm > nt_m || pn > nt_n) continue;
                 const int share = ((nt_m + pm - 1) / pm) * ((nt_n + pn - 1) / pn) * (split / pz);
                 if (share * 8 > total + total / 3 + 8) continue;
+                // (What the model leaves out: an XCD that runs its share in several rounds of 32 workgroups re-fetches its slice
+                // of A once per round or so - the weight panels streaming through the 4 MiB L2 evict it.  Measured, 1280 x 8192 x
+                // 1024 (80 workgroups per XCD): 149 MB fetched with either of the two best partitions, 75 / 88 MB by this formula.)
                 const double traffic = pn * A + pm * W;
                 if (!per_xcd || traffic < best) { best = traffic; map = TileMap{pz, pm, pn}; per_xcd = share; }
             }

@@ -93,10 +93,15 @@ def bench_config(beam=10, mtl=200, precision='f32_f16x3', vocab=3900):
     })
 
 
-def measured_traffic(kernel_class, precision):
+PMC_STEPS_PER_DECODE = 2          # the committed round-3 PMC passes ran the default command: 1280-row launches
+
+
+def measured_traffic(kernel_class, precision, steps_per_decode=PMC_STEPS_PER_DECODE):
     """HBM-side bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    collected and corrected by tools/pmc_traffic.py on this same command); None when that class was not profiled.
-    Later files (sorted by name: r02 after r01) win."""
+    collected and corrected by tools/pmc_traffic.py on this same command); None when that class was not profiled, or when
+    this run launches other row counts than the profiled command did.  Later files (sorted by name: r03 after r02) win."""
+    if steps_per_decode != PMC_STEPS_PER_DECODE:
+        return None
     best = None
     pdir = os.path.join(ROOT, 'profiles')
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -202,7 +207,7 @@ def identical_to_oracle(Y, Yc):
     return int(np.all(Yc[:, :m] == Y[:Yc.shape[0], :m], axis=1).sum())
 
 
-def roofline_of(prof, precision):
+def roofline_of(prof, precision, steps_per_decode=PMC_STEPS_PER_DECODE):
     overhead = [p for p in prof if p['name'].startswith('(')]
     prof = [p for p in prof if not p['name'].startswith('(')]
     tot_ms = sum(p['ms'] for p in prof) or 1.0
@@ -218,7 +223,7 @@ def roofline_of(prof, precision):
     r = {
         'kernel': dom['name'], 'bound': 'mfma' if is_mfma else 'hbm', 'achieved': ach,
         'peak': peak, 'unit': unit, 'frac': ach / peak,
-        'traffic': measured_traffic(dom['name'], precision),
+        'traffic': measured_traffic(dom['name'], precision, steps_per_decode),
         'launches': dom['launches'], 'avg_us': 1000.0 * dom['ms'] / max(dom['launches'], 1),
         'share_of_kernel_time': dom['ms'] / tot_ms,
         # elapsed time of an EMPTY HIP-event pair, already subtracted from every bracket (asr_set_profile)
@@ -722,7 +727,7 @@ def main():
             decode_call(eng, spd)
             solo = {p['name']: p for p in eng.get_profile()}
             eng.set_profile(0)
-        out['roofline'], out['kernels'] = roofline_of(prof, args.precision)
+        out['roofline'], out['kernels'] = roofline_of(prof, args.precision, spd)
         for k in out['kernels']:
             p1 = solo.get(k['name'])
             if p1 and p1['launches']:
@@ -748,7 +753,7 @@ def main():
               'algorithmic_gb': sum(p['bytes'] for p in prof if not p['name'].startswith('(')) / spd / 1e9}
         ws['algorithmic_gbs'] = ws['algorithmic_gb'] / step_s
         ws['algorithmic_frac_of_hbm_peak'] = ws['algorithmic_gbs'] / PEAK_HBM_GBS
-        tr = [(measured_traffic(p['name'], args.precision) or measured_traffic(p['name'] + '_reg', args.precision), p['launches'])
+        tr = [(measured_traffic(p['name'], args.precision, spd) or measured_traffic(p['name'] + '_reg', args.precision, spd), p['launches'])
               for p in prof if not p['name'].startswith('(')]
         if all(t is not None for t, _ in tr):
             # memory-side traffic (PMC FETCH_SIZE / WRITE_SIZE per launch, profiles/): reads that missed the L2s, served by

@@ -27,6 +27,8 @@ int main(int argc, char** argv)
         {"qkv   ", 640, 3072, 1024, EPI_PARTIAL}, {"proj  ", 640, 1024, 1024, EPI_PARTIAL},
         {"glu   ", 640, 8192, 1024, EPI_GLU},     {"xgluP ", 640, 8192, 1024, EPI_PARTIAL}, {"xgluB ", 640, 8192, 1024, EPI_BIAS},     {"ffn2  ", 640, 1024, 4096, EPI_PARTIAL},
         {"logits", 640, 3900, 1024, EPI_PARTIAL},
+        {"dqkv  ", 1280, 3072, 1024, EPI_PARTIAL}, {"dproj ", 1280, 1024, 1024, EPI_PARTIAL}, {"dglu  ", 1280, 8192, 1024, EPI_GLU},
+        {"dffn2 ", 1280, 1024, 4096, EPI_PARTIAL}, {"dlogit", 1280, 3900, 1024, EPI_PARTIAL},
         {"hqkv  ", 320, 3072, 1024, EPI_PARTIAL}, {"hproj ", 320, 1024, 1024, EPI_PARTIAL},
         {"hglu  ", 320, 8192, 1024, EPI_GLU},     {"hffn2 ", 320, 1024, 4096, EPI_PARTIAL},
         // fixed cost vs cost per k-tile: the same N at shorter K
@@ -40,7 +42,7 @@ int main(int argc, char** argv)
     size_t maxA = 0, maxW = 0, maxC = 0;
     for (auto& s : shapes) {
         maxA = std::max(maxA, (size_t)s.M * s.K); maxW = std::max(maxW, (size_t)s.N * s.K);
-        maxC = std::max(maxC, (size_t)s.M * s.N * (s.M <= 640 ? ASR_MAX_SPLITK : 1));
+        maxC = std::max(maxC, (size_t)s.M * s.N * (s.M <= 1280 ? ASR_MAX_SPLITK : 1));
     }
     const int npl = gemm_split_planes(nprod);
     float *A, *W, *C, *Cref, *bias;
@@ -66,7 +68,7 @@ int main(int argc, char** argv)
         const size_t wbytes = (planes.size() * 2 + 255) / 256 * 256;
         const int copies = cold ? (int)std::max<size_t>(1, POOL / wbytes) : 1;
         for (int c = 0; c < copies; ++c) CK(hipMemcpy(reinterpret_cast<char*>(Wp) + c * wbytes, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
-        const bool dec = s.M <= 640;
+        const bool dec = s.M <= 1280;
         const int ldc = s.epi == EPI_GLU ? s.N / 2 : s.N;
         // reference: exact-f32 kernel, unsplit
         GemmArgs r{};

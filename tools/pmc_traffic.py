@@ -40,11 +40,14 @@ def per_kernel(path):
     return acc
 
 
-# GEMM shapes of the char model at config 2 as bench.py's default run launches them (640 decode rows, 21376 encoder rows;
-# M x N x K, N of the GLU layer counts value and gate columns), for naming a grid
-MODEL_SHAPES = [(640, 3072, 1024), (640, 1024, 1024), (640, 8192, 1024), (640, 1024, 4096), (640, 3900, 1024),
-                (21376, 1024, 320), (21376, 3072, 1024), (21376, 1024, 1024), (21376, 8192, 1024), (21376, 1024, 4096),
-                (21376, 2048, 1024)]
+# GEMM shapes of the char model at config 2 as bench.py's default run launches them (two 64-utterance steps per call: 1280
+# decode rows; 21376 encoder rows per step, 42752 per call; M x N x K, N of the GLU layer counts value and gate columns),
+# for naming a grid.  PMC_ROWS=640 in the environment names the grids of a `--steps-per-decode 1` run instead.
+import os as _os
+_R = int(_os.environ.get('PMC_ROWS', '1280'))
+_E = 21376 * (_R // 640)
+MODEL_SHAPES = [(_R, 3072, 1024), (_R, 1024, 1024), (_R, 8192, 1024), (_R, 1024, 4096), (_R, 3900, 1024),
+                (_E, 1024, 320), (_E, 3072, 1024), (_E, 1024, 1024), (_E, 8192, 1024), (_E, 1024, 4096), (_E, 2048, 1024)]
 
 
 def shape_of(cls, wgs):
@@ -58,9 +61,17 @@ def shape_of(cls, wgs):
     for (M, N, K) in MODEL_SHAPES:
         if (epi == 'GLU') != (N == 8192):
             continue
-        tiles = -(-M // bm) * -(-N // bn)
+        nt_m, nt_n = -(-M // bm), -(-N // bn)
         for split in ((1,) if epi != 'PARTIAL' else (1, 2, 4, 8)):
-            if tiles * split == wgs:
+            grids = {nt_m * nt_n * split}                      # the legacy order: one workgroup per tile and K-slice
+            if nt_m <= 32:                                     # the per-XCD partition pads every XCD to the largest share
+                for pz in (1, 2, 4, 8):
+                    for pm in (1, 2, 4, 8):
+                        if split % pz == 0 and pm * pz <= 8:
+                            pn = 8 // (pm * pz)
+                            if pm <= nt_m and pn <= nt_n:
+                                grids.add(8 * -(-nt_m // pm) * -(-nt_n // pn) * (split // pz))
+            if wgs in grids:
                 hits.append('%dx%dx%d' % (M, N, K) + ('/%d' % split if split > 1 else ''))
     return hits[0] if len(hits) == 1 else ('|'.join(hits) if hits else None)
 
