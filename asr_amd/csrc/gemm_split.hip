@@ -214,10 +214,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4
                     const f32x4& x = ra[S][i][pr >> 1];
                     f32x2 v = {x[2 * (pr & 1)], x[2 * (pr & 1) + 1]};
                     if constexpr (F16) {
+#ifdef ASR_GEMM_NO_SPLIT       // measurement only (WRONG low plane, no range check): what the split's VALU work costs.  Same-box A/B of
+                               // the whole bench (round 3): 186.8 -> 183.0 ms per step with a non-zero low plane - what activations
+                               // split once by their producers could buy at most; with an all-zero low plane 183.7 -> 175.5 ms: the
+                               // chip is power-bound, a matrix instruction on zeros is cheaper than one on data
+                        const f16x2 b = __builtin_convertvector(v, f16x2);
+                        pieces[i][0][pr] = __builtin_bit_cast(uint32_t, b);
+                        pieces[i][1][pr] = __builtin_bit_cast(uint32_t, b) ^ 0x00550055u;
+#else
                         amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
                         const f16x2 b = __builtin_convertvector(v, f16x2);
                         pieces[i][0][pr] = __builtin_bit_cast(uint32_t, b);
                         rest[i] = (v - __builtin_convertvector(b, f32x2)) * F16X3_SCALE;          // exact
+#endif
                     } else {
                         const bf16x2 b = __builtin_convertvector(v, bf16x2);
                         pieces[i][0][pr] = __builtin_bit_cast(uint32_t, b);
@@ -227,7 +236,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 4
                 if (op == i * APASS + 2 * pr + 1) {
                     f32x2 v = rest[i];
                     if constexpr (F16) {
+#ifndef ASR_GEMM_NO_SPLIT
                         pieces[i][1][pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+#endif
                     } else {
 #pragma unroll
                         for (int pl = 1; pl < NPL; ++pl) {
