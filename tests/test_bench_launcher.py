@@ -71,3 +71,19 @@ def test_the_parent_module_imports_neither_torch_nor_the_hip_library():
             'assert "asr_amd._lib" not in sys.modules, "bench loads the HIP library at module level"; print("clean")')
     r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and 'clean' in r.stdout, r.stderr
+
+
+def test_plan_calls_gives_every_handle_the_same_number_of_steps():
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in range(0, 41):
+        for handles in (1, 2, 3, 4, 6):
+            for per_call in (1, 2, 3, 4):
+                calls = bench.plan_calls(k, handles, per_call)
+                assert sum(calls) == k and all(1 <= c <= per_call for c in calls)
+                assert calls == sorted(calls, reverse=True)                   # the large calls first
+                # no more calls than a handle-by-handle split needs: every handle's share in calls as large as allowed
+                share = [k // handles + (1 if i < k % handles else 0) for i in range(handles)]
+                assert len(calls) == sum(-(-s // per_call) for s in share)
+    assert bench.plan_calls(20, 4, 2) == [2] * 8 + [1] * 4
+    assert bench.plan_calls(8, 4, 2) == [2] * 4
