@@ -30,6 +30,16 @@ constexpr int NOALLOC_MAX_UTTS = 1024;
 constexpr int NOALLOC_DOUBLES_PER_UTT = 128;
 constexpr int MAX_DEVICES = 64;
 constexpr int MAX_VIEWS = 4;        // sub-batches a beam search may run as (asr_config.sub_batches)
+// Handles that share the GPU choose the K-slices of their decode-row GEMMs independently of the row count from this many beam
+// rows up (decode_splits, logit_split_for): a whole batch and a joint decode of two or more of them then sum in the same order,
+// which is what lets asr_amd.model pair whole batches with bit-identical hypotheses (PAIR_MIN_ROWS there is this number).
+// 448 = 45 utterances at beam 10: BASELINE config 5's 50-utterance batches count as whole.
+constexpr int WHOLE_BATCH_ROWS_DEFAULT = 448;
+static int whole_batch_rows()
+{
+    static const int v = [] { const char* e = getenv("ASR_AMD_WHOLE_ROWS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : WHOLE_BATCH_ROWS_DEFAULT; }();   // (development)
+    return v;
+}
 static __device__ __align__(256) double g_norm_scratch[NOALLOC_MAX_UTTS * NOALLOC_DOUBLES_PER_UTT];
 double* g_norm_scratch_ptr[MAX_DEVICES] = {};      // device address of g_norm_scratch on device d (null: not resolved yet)
 std::mutex g_norm_scratch_mu[MAX_DEVICES];         // held while a device's entry is resolved (asr_create) and, by the allocation-free
@@ -92,7 +102,7 @@ struct asr_handle {
     int32_t* grp_buf = nullptr;         // device home of those arrays and of the per-utterance loop limits: [3][grp_cap]
     size_t grp_cap = 0;
     int logit_split = 1;                // K slices of the logits GEMM (their slabs are summed by the top-k kernel)
-    int logit_split_shared = 2;         // ... of handles that share the GPU, from 576 beam rows (env ASR_AMD_LOGIT_SPLIT_SHARED: development)
+    int logit_split_shared = 2;         // ... of handles that share the GPU, from whole_batch_rows() beam rows (env ASR_AMD_LOGIT_SPLIT_SHARED: development)
     float* emb_gemm = nullptr;          // logits operand when tied: = emb (f32 mode) or its bf16 planes
     hipStream_t stream = nullptr;
     mutable std::string err;
@@ -562,7 +572,7 @@ int decode_splits(const asr_handle* h, int R, int* s_qkv, int* s_proj, int* s_ff
     // (ms per batch): 2,2,8 (the values above) 212.3; 1,1,1 219.4; 1,1,2 204.8; 1,1,4 205.3; 1,2,4 206.5; 2,2,4 208.4; 1,1,8 208.8.
     // Ten-utterance batches lose with fewer slices (1377 -> 1160 audio-s/s): only for whole-batch row counts.
     // One-product mode (bf16), same sweep: 1,1,2 125.9; 1,1,4 122.2; 1,2,4 123.7; 2,2,4 126.0; 2,2,8 128.9; 1,1,1 132.0.
-    if (h->shared_gpu && R >= 576) { *s_qkv = 1; *s_proj = 1; *s_ffn2 = h->nprod_active == 1 ? 4 : 2; }
+    if (h->shared_gpu && R >= whole_batch_rows()) { *s_qkv = 1; *s_proj = 1; *s_ffn2 = h->nprod_active == 1 ? 4 : 2; }
     if (const char* e = getenv("ASR_AMD_SPLITS")) {                  // development: "qkv,proj,ffn2"
         int a = 0, b = 0, c = 0;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 1 && b >= 1 && c >= 1 && a <= ASR_MAX_SPLITK && b <= ASR_MAX_SPLITK &&
@@ -577,7 +587,7 @@ int decode_splits(const asr_handle* h, int R, int* s_qkv, int* s_proj, int* s_ff
 int logit_split_for(const asr_handle* h, int R)
 {
     if (const char* e = getenv("ASR_AMD_LOGIT_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2) return v; }
-    if (h->shared_gpu && R >= 576) return h->logit_split_shared;
+    if (h->shared_gpu && R >= whole_batch_rows()) return h->logit_split_shared;
     return std::min(2, gemm_pick_split_k(R, h->V, h->H, gemm_nprod(h, h->H)));
 }
 

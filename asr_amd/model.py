@@ -28,7 +28,7 @@ from .utils import shard_bounds
 DEFAULT_PRECISION = 'f32_f16x3'
 # beam rows from which a handle that shares the GPU picks its K-slices independently of the row count (engine.hip decode_splits,
 # logit_split_for): batches of at least that many rows can be decoded in pairs with bit-identical hypotheses
-PAIR_MIN_ROWS = 576
+PAIR_MIN_ROWS = 448                 # = engine.hip WHOLE_BATCH_ROWS_DEFAULT: from here on a shared GPU's K-slices do not follow the row count
 
 
 def asr_config_from(config, device=0):
@@ -539,7 +539,7 @@ class Model(object):
                 pair = os.environ.get('ASR_AMD_PAIR_BATCHES', '1') != '0'
             if not pair:
                 return self.pools[0].map(lambda e, X: e.decode(np.asarray(X, dtype=np.float32)), batches)
-            # Whole batches (576 beam rows or more each) are decoded two per library call (Engine.decode_groups): every weight
+            # Whole batches (PAIR_MIN_ROWS beam rows or more each) are decoded two per library call (Engine.decode_groups): every weight
             # plane is streamed once for both.  From that row count on the handles of a pool choose the same K-slices whatever the
             # number of rows, so every float32 sum is taken in the same order as in a call of the batch alone: the SAME hypotheses,
             # bit for bit (`test.pair_batches: false` / ASR_AMD_PAIR_BATCHES=0 turns it off).  Smaller batches go one per call.

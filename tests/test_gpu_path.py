@@ -309,7 +309,7 @@ def test_full_size_batch64_properties():
 
 
 def test_shared_gpu_handles_use_fewer_k_slices_and_give_the_same_hypotheses():
-    """asr_config.shared_gpu = 1 (what EnginePool sets on its handles): from 576 beam rows up the decode-row GEMMs run with
+    """asr_config.shared_gpu = 1 (what EnginePool sets on its handles): from 448 beam rows up the decode-row GEMMs run with
     fewer K-slices (another summation order, same arithmetic).  Full-size char architecture, 64 short utterances x beam 10
     = 640 rows: tokens and parents of every step identical to the float32 oracle, logits within 1e-3, in both settings."""
     from asr_amd.model import Engine

@@ -73,7 +73,7 @@ def test_handles_of_a_pool_share_one_weight_store():
 
 def test_pool_regimes_alone_and_together_give_the_oracles_hypotheses():
     """A handle of a pool used alone (Model.predict) runs in the regime of a handle that has the GPU to itself; inside
-    EnginePool.map / together() all handles run in the shared-GPU regime (fewer K-slices from 576 beam rows, one run of
+    EnginePool.map / together() all handles run in the shared-GPU regime (fewer K-slices from 448 beam rows, one run of
     kernels per batch).  Full-size char architecture, 64 short utterances x beam 10 = 640 rows, 5 steps: the float32
     oracle's hypotheses in both regimes, and asr_set_sharing refuses values outside its ranges."""
     from asr_amd._lib import AsrError
@@ -182,15 +182,15 @@ def test_evaluate_as_one_process_per_gpu_writes_the_single_process_file(tmp_path
 
 
 def test_whole_batches_are_decoded_in_pairs_with_bit_identical_hypotheses():
-    """Model.predict_batches with several handles: consecutive batches of at least 576 beam rows go two per library call
+    """Model.predict_batches with several handles: consecutive batches of at least 448 beam rows go two per library call
     (Engine.decode_groups; one pass over every weight plane for both).  From that row count on a pool's handles pick their
     K-slices independently of the number of rows, so the pair must reproduce the one-batch-per-call hypotheses BIT for bit:
-    full-size char architecture, batches of 64 / 60 / 64 / 20 utterances with different padded lengths, beam 10, and the
+    full-size char architecture, batches of 64 / 60 / 50 / 64 / 20 utterances with different padded lengths, beam 10, and the
     float32 oracle's hypotheses for every batch."""
     from asr_amd.model import Model
     ocfg = O.make_config(beam_size=10, max_target_length=4)
     W = O.random_weights(ocfg, seed=51)
-    shapes = [(64, 90), (60, 120), (64, 75), (20, 60)]
+    shapes = [(64, 90), (60, 120), (50, 75), (64, 81), (20, 60)]
     Xs = [O.make_batch(O.synthetic_fbank(n, [top - 3 * (i % 5) for i in range(n)], seed=300 + j)) for j, (n, top) in enumerate(shapes)]
     want = [O.build_test_model(X, W, ocfg, num_gpus=1, algo='kv') for X in Xs]
     got = {}
@@ -210,7 +210,7 @@ def test_whole_batches_are_decoded_in_pairs_with_bit_identical_hypotheses():
             got[pair] = list(m.predict_batches(iter(Xs)))
         finally:
             m.close()
-        assert sorted(calls) == ([[20], [64], [64, 60]] if pair else [[20], [60], [64], [64]])
+        assert sorted(calls) == ([[20], [50, 64], [64, 60]] if pair else [[20], [50], [60], [64], [64]])
     for Yp, Y1, Yw in zip(got[True], got[False], want):
         assert Yp.shape == Y1.shape and np.array_equal(Yp, Y1)          # paired == alone, bit for bit
         assert np.array_equal(Y1, Yw)                                    # == the oracle's

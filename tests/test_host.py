@@ -362,7 +362,7 @@ def test_model_defaults_to_the_measured_handle_count(monkeypatch):
 
 
 def test_predict_batches_pairs_whole_batches_and_keeps_their_order():
-    """Without `test.merge_utts`, a pool of several handles decodes consecutive WHOLE batches (>= 576 beam rows each) two per
+    """Without `test.merge_utts`, a pool of several handles decodes consecutive WHOLE batches (>= 448 beam rows each) two per
     call and everything else one per call; results come back batch by batch in order; `test.pair_batches: false` turns it off."""
     from asr_amd.model import EnginePool, Model
     calls = []
@@ -382,7 +382,7 @@ def test_predict_batches_pairs_whole_batches_and_keeps_their_order():
             pass
 
     def batches():
-        for n, t in [(64, 10), (64, 11), (64, 12), (5, 13), (64, 14), (60, 15), (57, 16), (64, 17)]:
+        for n, t in [(64, 10), (64, 11), (64, 12), (5, 13), (64, 14), (60, 15), (44, 16), (64, 17), (45, 18), (50, 19)]:
             yield np.zeros((n, t, 4), np.float32)
     for pair in (None, False):
         cfg = product_config(tiny_config(beam_size=10))
@@ -394,9 +394,9 @@ def test_predict_batches_pairs_whole_batches_and_keeps_their_order():
         m.pools, m.engines = [pool], [pool.engines[0]]
         calls[:] = []
         out = list(m.predict_batches(batches()))
-        assert [int(y[0, 0]) for y in out] == [10, 11, 12, 13, 14, 15, 16, 17]
-        assert [y.shape[0] for y in out] == [64, 64, 64, 5, 64, 60, 57, 64]
+        assert [int(y[0, 0]) for y in out] == [10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+        assert [y.shape[0] for y in out] == [64, 64, 64, 5, 64, 60, 44, 64, 45, 50]
         if pair is None:
-            assert sorted(calls) == sorted([[64, 64], [64], [5], [64, 60], [57], [64]])
+            assert sorted(calls) == sorted([[64, 64], [64], [5], [64, 60], [44], [64, 45], [50]])
         else:
-            assert sorted(calls) == sorted([[64], [64], [64], [5], [64], [60], [57], [64]])
+            assert sorted(calls) == sorted([[64], [64], [64], [5], [64], [60], [44], [64], [45], [50]])
