@@ -333,7 +333,7 @@ const char* gemm_class_name(const asr_handle* h, int nprod, int M, int N, int K,
     static std::mutex interned_mu;                                // handles on other GPUs / other host threads share it
     const int tile = nprod == 0 ? gemm_f32_pick_tile(M, N, split_k, epilogue) : split_tile_for(h, M, N, K, split_k, epilogue);
     std::string n = nprod == 0 ? "gemm_f32_nt" : nprod == 13 ? "gemm_f16x3_nt" : nprod == 6 ? "gemm_bf16x6_nt" : nprod == 3 ? "gemm_bf16x3_nt" : "gemm_bf16_nt";
-    if (nprod) n += tile == 1 ? "<128,128," : tile == 5 ? "<160,128," : tile == 6 ? "<96,256," : tile == 7 || tile == 9 ? "<64,256," : "<64,128,";
+    if (nprod) n += tile == 1 ? "<128,128," : tile == 5 ? "<160,128," : tile == 6 ? "<96,256," : tile == 10 ? "<128,256," : tile == 7 || tile == 9 ? "<64,256," : "<64,128,";
     else n += tile == 1 ? "<128,128," : tile == 4 ? "<128,64," : "<64,64,";
     n += epilogue == EPI_GLU ? "GLU>" : epilogue == EPI_PARTIAL ? "PARTIAL>" : epilogue == EPI_BIAS ? "BIAS>" : "ACT>";
     std::lock_guard<std::mutex> lock(interned_mu);

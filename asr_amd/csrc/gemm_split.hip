@@ -476,8 +476,11 @@ hipError_t launch_split_epi(const GemmArgs& a, int tile, hipStream_t s)
 #ifdef ASR_GEMM_ALL_TILES
         case 3: return launch_split_tile<1, 1, 4, EPI, NPROD>(a, s);     // 32 x 128
         case 4: return launch_split_tile<1, 1, 8, EPI, NPROD>(a, s);     // 32 x 256, 8 waves of 32 columns
+        case 11: return launch_split_tile<5, 1, 8, EPI, NPROD>(a, s);    // 160 x 256
+        case 12: return launch_split_tile<4, 2, 4, EPI, NPROD>(a, s);    // 128 x 256, 4 waves of 64 columns
 #endif
         case 6: return launch_split_tile<3, 1, 8, EPI, NPROD>(a, s);     // 96 x 256, 8 waves of 32 columns
+        case 10: return launch_split_tile<4, 1, 8, EPI, NPROD>(a, s);    // 128 x 256, 8 waves of 32 columns
         case 9: return launch_split_tile<2, 1, 8, EPI, NPROD>(a, s);     // 64 x 256, 8 waves of 32 columns
         default: return launch_split_tile<2, 1, 4, EPI, NPROD>(a, s);    // 64 x 128
     }
@@ -616,6 +619,8 @@ int gemm_split_pick_tile(int M, int N, int K, int split_k, int epilogue)
 {
     const int ts = tall_slices(M, N, K, epilogue == EPI_PARTIAL);
     if (ts && ts == std::max(1, split_k)) return 6;
+    static const int enc_tile = getenv("ASR_AMD_ENC_TILE") ? atoi(getenv("ASR_AMD_ENC_TILE")) : 10;     // development
+    if (M > 4096 && std::max(1, split_k) == 1 && (enc_tile == 6 || enc_tile == 9 || enc_tile == 10)) return enc_tile;
     return legacy_tile(M, N, K);
 }
 

@@ -470,19 +470,26 @@ class Model(object):
         epg = (config.test.engines_per_gpu if config.test else None) or os.environ.get('ASR_AMD_ENGINES')
         if epg:
             self._engines_per_gpu = max(1, int(epg))
-        elif self._num_towers == 1:
-            q = hwqueues.ensure()
-            self._engines_per_gpu = 4 if q['value'] >= hwqueues.WANTED else 3
-            logging.info('asr_amd: test.engines_per_gpu unset: %d engine handles per GPU on %d hardware queues (%s)',
-                         self._engines_per_gpu, q['value'], q['source'])
         else:
-            self._engines_per_gpu = 1
+            self._engines_per_gpu = None                             # decided below, once the devices are known
         if devices is None:
             if 'LOCAL_RANK' in os.environ or 'ASR_AMD_DEVICE' in os.environ:
                 devices = [default_device()]
             else:
                 devices = list(range(max(1, min(self._num_towers, visible_devices()))))
         self._devices = list(devices)
+        # build extension `test.joint_towers` (default true; env ASR_AMD_JOINT_TOWERS=0): towers that share a GPU are decoded by one
+        # joint call; false = one call per tower, one after the other
+        jt = config.test.joint_towers if config.test else None
+        self._joint_towers = (os.environ.get('ASR_AMD_JOINT_TOWERS', '1') != '0') if jt is None else bool(jt)
+        if self._engines_per_gpu is None:
+            if len(self._devices) == 1:                              # one GPU for this process, however many towers the YAML names
+                q = hwqueues.ensure()
+                self._engines_per_gpu = 4 if q['value'] >= hwqueues.WANTED else 3
+                logging.info('asr_amd: test.engines_per_gpu unset: %d engine handles per GPU on %d hardware queues (%s)',
+                             self._engines_per_gpu, q['value'], q['source'])
+            else:
+                self._engines_per_gpu = 1
         self.pools = []
         self.engines = []
         self.encoder_scope = 'encoder'
@@ -567,20 +574,40 @@ class Model(object):
             def call(e, Xs):
                 return [e.decode(Xs[0])] if len(Xs) == 1 else e.decode_groups(Xs)
             return (Y for Ys in self.pools[0].map(call, paired()) for Y in Ys)
+        if self._num_towers > 1 and len(self.pools) == 1 and len(self.pools[0].engines) > 1:
+            # the YAML names several towers (the reference's configs ship `test.num_gpus: 4`) and this process has one GPU: every
+            # batch is still split into its towers' shards (below), and that many batches are in flight over the pool's handles
+            return self.pools[0].map(lambda e, X: self._predict_on([e], X), batches)
         return (self.predict(X) for X in batches)
 
     def predict(self, X):
         """== sess.run(self.prediction, expand_feed_dict({self.src_pls: X}))."""
+        return self._predict_on(self.engines, X)
+
+    def _predict_on(self, engines, X):
+        """model.py:168-201 on `engines` (one per GPU): dim 0 split into the towers' shards exactly as expand_feed_dict does,
+        every shard decoded as a beam search of its own (its own loop end and prediction length), predictions padded with 3 to
+        the longest and concatenated in tower order.  Towers that land on the same GPU are decoded by ONE joint call
+        (Engine.decode_groups: the shards stay groups of their own wherever that enters the arithmetic, the row-wise
+        kernels run over all of them - one pass over the weights instead of one per tower)."""
         X = np.asarray(X, dtype=np.float32)
         bounds = shard_bounds(X.shape[0], self._num_towers)
         preds = [None] * self._num_towers
         by_engine = {}
         for i, (a, b) in enumerate(bounds):
-            by_engine.setdefault(i % len(self.engines), []).append((i, a, b))
+            by_engine.setdefault(i % len(engines), []).append((i, a, b))
 
         def work(ei, items):
+            full = [(i, a, b) for (i, a, b) in items if b > a]
             for (i, a, b) in items:
-                preds[i] = self.engines[ei].decode(X[a:b]) if b > a else np.zeros((0, 0), np.int32)   # model.py:184-187
+                if b <= a:
+                    preds[i] = np.zeros((0, 0), np.int32)                                            # model.py:184-187
+            if len(full) == 1 or not self._joint_towers:
+                for (i, a, b) in full:
+                    preds[i] = engines[ei].decode(X[a:b])
+            elif full:
+                for (i, a, b), Y in zip(full, engines[ei].decode_groups([X[a:b] for (_, a, b) in full])):
+                    preds[i] = Y
 
         if len(by_engine) == 1:
             work(*next(iter(by_engine.items())))

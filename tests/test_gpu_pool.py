@@ -214,3 +214,42 @@ def test_whole_batches_are_decoded_in_pairs_with_bit_identical_hypotheses():
     for Yp, Y1, Yw in zip(got[True], got[False], want):
         assert Yp.shape == Y1.shape and np.array_equal(Yp, Y1)          # paired == alone, bit for bit
         assert np.array_equal(Y1, Yw)                                    # == the oracle's
+
+
+def test_the_shipped_test_section_four_towers_on_one_gpu():
+    """`test.num_gpus: 4`, `beam_size: 13` (the test section the reference's char YAML ships, config_template_char_...yaml:49-54)
+    in a process with one GPU: every batch is split into four shards as expand_feed_dict does (utils.py:420-443), the four
+    shards are ONE joint decode (676 beam rows here), predictions are padded with 3 and concatenated in tower order
+    (model.py:192-201).  Full-size char architecture; hypotheses identical to the oracle's four-tower evaluation, and
+    predict_batches (several batches in flight over the default pool) returns what predict gives batch by batch; with
+    `test.joint_towers: false` the towers are decoded one after the other and give the same."""
+    from asr_amd.model import Model
+    ocfg = O.make_config(beam_size=13, max_target_length=4)
+    W = O.random_weights(ocfg, seed=61)
+    Xs = [O.make_batch(O.synthetic_fbank(n, [top - 3 * (i % 6) for i in range(n)], seed=400 + j)) for j, (n, top) in enumerate([(52, 90), (50, 75), (3, 60)])]
+    want = [O.build_test_model(X, W, ocfg, num_gpus=4, algo='kv') for X in Xs]
+    for joint in (True, False):
+        cfg = product_config(ocfg, 4)
+        cfg.test['joint_towers'] = joint
+        m = Model(cfg, 4, devices=[0])
+        assert m._engines_per_gpu in (3, 4)                                # the default pool, although the YAML names four towers
+        m.build_test_model()
+        m.restore(W)
+        calls = []
+        for e in m.pools[0].engines:
+            dg, dc = e.decode_groups, e.decode
+            e.decode_groups = lambda Xg, dg=dg: (calls.append([X.shape[0] for X in Xg]), dg(Xg))[1]
+            e.decode = lambda X, dc=dc: (calls.append([X.shape[0]]), dc(X))[1]
+        try:
+            one = [m.predict(X) for X in Xs]
+            n1 = len(calls)
+            many = list(m.predict_batches(iter(Xs)))
+        finally:
+            m.close()
+        if joint:
+            assert calls[:n1] == [[13, 13, 13, 13], [13, 13, 12, 12], [1, 1, 1]]
+        else:
+            assert calls[:n1] == [[13]] * 4 + [[13], [13], [12], [12]] + [[1]] * 3
+        for Y1, Ym, Yw in zip(one, many, want):
+            assert np.array_equal(Y1, Yw)
+            assert np.array_equal(Ym, Yw)

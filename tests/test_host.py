@@ -358,7 +358,56 @@ def test_model_defaults_to_the_measured_handle_count(monkeypatch):
     monkeypatch.setenv('ASR_AMD_ENGINES', '1')
     assert Model(product_config(ocfg), 1)._engines_per_gpu == 1
     monkeypatch.delenv('ASR_AMD_ENGINES')
-    assert Model(product_config(ocfg, num_gpus=3), 3)._engines_per_gpu == 1
+    # several towers: on ONE GPU (this process's) the same default - their shards are decoded jointly and batches go over the
+    # pool; towers on GPUs of their own keep one handle per GPU
+    assert Model(product_config(ocfg, num_gpus=3), 3)._engines_per_gpu == 3
+    assert Model(product_config(ocfg, num_gpus=3), 3, devices=[0, 1, 2])._engines_per_gpu == 1
+
+
+def test_towers_on_one_gpu_are_one_joint_decode_and_batches_go_over_the_pool():
+    """`test.num_gpus: 4` (what the reference's YAMLs ship) in a process with one GPU: every batch is split into its towers'
+    shards exactly as expand_feed_dict does (utils.py:420-443), the shards of one GPU are ONE decode_groups call, empty shards
+    give no rows (model.py:184-187), predictions are padded with 3 to the longest and concatenated in tower order
+    (model.py:192-201); predict_batches keeps several batches in flight over the pool and returns them in order."""
+    from asr_amd.model import EnginePool, Model
+    calls = []
+
+    class Fake(object):
+        _h = 1
+
+        def decode(self, X):
+            calls.append(('decode', [X.shape[0]]))
+            return np.full((X.shape[0], 2), int(X[0, 0, 0]), np.int32)
+
+        def decode_groups(self, Xs):
+            calls.append(('groups', [X.shape[0] for X in Xs]))
+            # group g answers with g + 2 columns of its first feature value
+            return [np.full((X.shape[0], 2 + g), int(X[0, 0, 0]), np.int32) for g, X in enumerate(Xs)]
+
+        def set_sharing(self, *a):
+            pass
+
+    cfg = product_config(tiny_config(beam_size=2), num_gpus=4)
+    m = Model(cfg, 4, devices=[0])
+    pool = object.__new__(EnginePool)
+    pool.engines = [Fake(), Fake()]
+    m.pools, m.engines = [pool], [pool.engines[0]]
+    X = np.zeros((10, 5, 4), np.float32)
+    X[:, 0, 0] = np.arange(10) + 10                       # utterance u carries 10 + u
+    Y = m.predict(X)                                      # shards 3, 3, 2, 2 (the first N % n shards get one more)
+    assert calls == [('groups', [3, 3, 2, 2])]
+    assert Y.shape == (10, 5) and [int(v) for v in Y[:, 0]] == [10] * 3 + [13] * 3 + [16] * 2 + [18] * 2
+    assert np.all(Y[0:3, 2:] == 3) and np.all(Y[3:6, 3:] == 3) and np.all(Y[8:10, :5] == 18)       # padded with 3 to the longest
+    calls[:] = []
+    Y = m.predict(X[:2])                                  # shards 1, 1, 0, 0: the empty towers give no rows
+    assert calls == [('groups', [1, 1])] and Y.shape[0] == 2
+    calls[:] = []
+    Y = m.predict(X[:1])                                  # one shard with rows: a plain decode
+    assert calls == [('decode', [1])] and Y.shape == (1, 2)
+    calls[:] = []
+    out = list(m.predict_batches(iter([X, X[:6], X[:3]])))
+    assert [y.shape[0] for y in out] == [10, 6, 3]
+    assert sorted(c[1] for c in calls) == sorted([[3, 3, 2, 2], [2, 2, 1, 1], [1, 1, 1]])
 
 
 def test_predict_batches_pairs_whole_batches_and_keeps_their_order():

@@ -85,7 +85,7 @@ int main(int argc, char** argv)
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             printf("%s M=%5d N=%5d K=%5d exact f32 (unsplit)      %8.1f us\n", s.name, s.M, s.N, s.K, ms * 1e3 / reps);
         }
-        for (int tile : {2, 3, 4, 9}) {
+        for (int tile : {2, 6, 9, 10, 11, 12}) {
             for (int split = 1; split <= (dec && s.epi == EPI_PARTIAL ? 16 : 1); split *= 2) {
                 if (split > 1 && s.K / split < 128) continue;
                 if ((only_tile && tile != only_tile) || (only_split && split != only_split)) continue;
