@@ -45,7 +45,7 @@ void gemm_force_reg_stage(bool on);
 // products; operands must fit fp16's range, see GemmArgs.range_flag), 6 (f32 accuracy by six bf16 products), 3 or 1 (bf16).
 // Needs K % 32 == 0 and a.Wp = the weight matrix as made by gemm_split_weights_host (gemm_split_planes(nprod) bf16 planes in
 // the kernel's panel order; gemm_split_weight_elems() uint16 elements).
-// tile_hint: 0 = choose from the shape, 2 = 64x128, 9 = 64x256 (8 waves) (M x N); with -DASR_GEMM_ALL_TILES also 1 = 128x128,
+// tile_hint: 0 = choose from the shape, 2 = 64x128, 9 = 64x256 (8 waves), 6 = 96x256, 10 = 128x256 (M x N); with -DASR_GEMM_ALL_TILES also 1 = 128x128,
 // 5 = 160x128, 7 = 64x256 (4 waves); an unknown hint runs 64x128
 hipError_t launch_gemm_split(const GemmArgs& a, int nprod, int tile_hint, hipStream_t s);
 int gemm_split_pick_tile(int M, int N, int K, int split_k, int epilogue);

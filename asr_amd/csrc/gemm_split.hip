@@ -619,7 +619,13 @@ int gemm_split_pick_tile(int M, int N, int K, int split_k, int epilogue)
 {
     const int ts = tall_slices(M, N, K, epilogue == EPI_PARTIAL);
     if (ts && ts == std::max(1, split_k)) return 6;
-    static const int enc_tile = getenv("ASR_AMD_ENC_TILE") ? atoi(getenv("ASR_AMD_ENC_TILE")) : 10;     // development
+    // Many rows (the encoder's 21376 .. 100000, the teacher-forced decoder): 128 x 256 tiles.  Every weight fragment a wave loads
+    // serves four 32-row MFMA blocks instead of two, i.e. half the L2 -> register weight traffic per product.  Round 3, alone on the
+    // GPU (tools/gemm_split_bench, 21376 rows, fp16x3): QKV 541 -> 480 us, GLU 1274 -> 1174, FFN2 656 -> 620, projections 161 -> 145
+    // (bf16: FFN2 317 -> 265, QKV 225 -> 210); 160 x 256 spills.  With four handles sharing the GPU, whole bench: 186.9 -> 185.9 ms
+    // per step, config 5 (50 x 30 s) +0.8 % / bf16 +1.8 %.  (Round 1 measured 64-row tiles ahead for these rows too - with the
+    // 4-wave kernel of that time.)  ASR_AMD_ENC_TILE=6|9|10: development.
+    static const int enc_tile = getenv("ASR_AMD_ENC_TILE") ? atoi(getenv("ASR_AMD_ENC_TILE")) : 10;
     if (M > 4096 && std::max(1, split_k) == 1 && (enc_tile == 6 || enc_tile == 9 || enc_tile == 10)) return enc_tile;
     return legacy_tile(M, N, K);
 }
