@@ -125,11 +125,13 @@ hipError_t launch_beam_prune(const float* scores, const int32_t* finished, const
                              int32_t* parents, int32_t* finished_out, hipStream_t s);
 
 // ---- attention (attention.hip) ---------------------------------------------------------------
+// mode: 13 = products as three fp16 MFMAs (f32_f16x3; operands outside fp16's range set *range_flag), 1 = bf16 K / V with
+// two-term q and P (`precision: bf16`), anything else = the exact-f32 matrix instruction
 hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads,
-                                    float* ctx, hipStream_t s);
+                                    float* ctx, int mode, int32_t* range_flag, hipStream_t s);
 // general many-query attention: q rows [n*tq] (stride ldq), k / v rows [n*tk]; pad [n][tk] or null; causal needs tq == tk
 hipError_t launch_mha(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* pad, int causal,
-                      int n, int tq, int tk, int heads, float* ctx, hipStream_t s);
+                      int n, int tq, int tk, int heads, float* ctx, int mode, int32_t* range_flag, hipStream_t s);
 struct SelfAttnArgs {
     const float* qkv;      // [nsplit][R][3*hidden] partial qkv projections (q | k | v), bias not yet added
     int nsplit; size_t split_stride;

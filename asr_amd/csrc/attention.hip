@@ -791,22 +791,246 @@ void decoder_cross_attention_kernel(CrossAttnArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The many-query attention on the 16-bit matrix instruction (v_mfma_f32_32x32x16_*: 8 passes for 16 k-values where the exact-f32
+// instruction above takes 16 passes for 2), same grid, same operand roles (S^T = K.Q^T, O^T += V^T.P^T, a lane owns a query).
+//   MODE 13 (`f32_f16x3`): every operand as x1 + 2^-11 x2 (fp16 pair, as gemm_split.hip and the decode-time cross-attention do):
+//           three products per multiply, the 2^-11 group in accumulators of its own; operands must fit fp16 (range_flag -> the
+//           engine repeats the call on the exact-f32 kernel);
+//   MODE 1  (`bf16`): K and V rounded to bf16 (what the decode-time kernels' bf16 caches hold), q and P as two bf16 terms.
+// K / V tiles are split ONCE per workgroup on their way into LDS: K planes [key][8 x 16 B] (chunk ^ (key & 7)), V planes
+// TRANSPOSED [d][8 x 8 B] (four keys a chunk, chunk ^ ((d >> 1) & 7)) so that a lane's A operand of O^T += V^T.P^T - eight keys
+// of one d - is two 8-byte reads.  The k index of the second product is a summation label only: key(s, half, j) =
+// 16 s + 8 (j >> 2) + 4 half + (j & 3) is the order in which a lane's S^T accumulator already holds its 16 keys, so P goes from
+// the accumulator into the B operand without leaving the lane.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int MODE> __device__ __forceinline__ f32x16 mma32x16(const u32x4_t& a, const u32x4_t& b, const f32x16& c)
+{
+    if constexpr (MODE == 13) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// x -> (first term, second term) of 8 values; MODE 13: fp16 pair with the 2^11 scale, MODE 1: bf16 pair
+template <int MODE> __device__ __forceinline__ void split8(const f32x8_t& x, u32x4_t& hi, u32x4_t& lo)
+{
+    if constexpr (MODE == 13) {
+        const f16x8_t h = __builtin_convertvector(x, f16x8_t);
+        hi = __builtin_bit_cast(u32x4_t, h);
+        lo = __builtin_bit_cast(u32x4_t, __builtin_convertvector((x - __builtin_convertvector(h, f32x8_t)) * ATT_F16_SCALE, f16x8_t));
+    } else {
+        const bf16x8_t h = __builtin_convertvector(x, bf16x8_t);
+        hi = __builtin_bit_cast(u32x4_t, h);
+        lo = __builtin_bit_cast(u32x4_t, __builtin_convertvector(x - __builtin_convertvector(h, f32x8_t), bf16x8_t));
+    }
+}
+__device__ __forceinline__ float absmax8(const f32x8_t& x)
+{
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(x[i]));
+    return m;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void encoder_attention16_kernel(MhaArgs a, int32_t* range_flag)
+{
+    constexpr bool F16 = MODE == 13;
+    constexpr int NPL = F16 ? 2 : 1;               // planes of K and V in LDS (bf16: one term)
+    __shared__ u32x4_t Ks[NPL][32 * 8];            // [plane][key][16-B chunk of 8 d ^ (key & 7)]
+    __shared__ u32x2_t Vt[NPL][64 * 8];            // [plane][d][8-B chunk of 4 keys ^ ((d >> 1) & 7)]
+    __shared__ float Bias[32];
+    __shared__ float Os[4][32][65];
+
+    const int qt = blockIdx.x, h = blockIdx.y, u = blockIdx.z;
+    const int hidden = a.heads * 64;
+    const int t = a.tq, tk = a.tk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int q0w = qt * 128 + wave * 32;
+    const int q = q0w + l31;
+    const float* qbase = a.q + (size_t)u * t * a.ldq;
+    const float* kbase = a.k + (size_t)u * tk * a.ldk;
+    const float* vbase = a.v + (size_t)u * tk * a.ldv;
+    const int32_t* pad = a.pad;
+    float* ctx = a.ctx;
+    float amax = 0.f;                              // MODE 13: the largest magnitude this thread has split
+
+    // q fragments: B operand of S^T = K.Q^T, lane (query l31, half) holds d = 16 s + 8 half .. + 8 of k-step s
+    u32x4_t qh[4], ql[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        f32x8_t v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (q < t) {
+            const float* p = qbase + (size_t)q * a.ldq + h * 64 + 16 * s4 + 8 * half;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+            v = f32x8_t{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]} * 0.125f;   // q *= key_depth_per_head ** -0.5 (utils.py:628)
+        }
+        if constexpr (F16) amax = fmaxf(amax, absmax8(v));
+        split8<MODE>(v, qh[s4], ql[s4]);
+    }
+
+    f32x16 o[2], o2[F16 ? 2 : 1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; o2[0][r] = 0.f; if constexpr (F16) o2[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging roles: K - thread -> (key = tid / 8, 8 d at 8 (tid % 8)); V - thread -> (4 keys at 4 (tid / 32), 2 d at 2 (tid % 32))
+    const int skey = tid >> 3, sc = tid & 7;
+    const int vkg = tid >> 5, vdp = tid & 31;
+
+    int nkt = (tk + 31) / 32;
+    if (a.causal) nkt = min(nkt, (min(qt * 128 + 127, t - 1) >> 5) + 1);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 32;
+        {
+            f32x8_t kv = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (k0 + skey < tk) {
+                const float* p = kbase + (size_t)(k0 + skey) * a.ldk + h * 64 + 8 * sc;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+                kv = f32x8_t{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            }
+            f32x2 vv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                vv[r] = f32x2{0.f, 0.f};
+                if (k0 + 4 * vkg + r < tk) vv[r] = *reinterpret_cast<const f32x2*>(vbase + (size_t)(k0 + 4 * vkg + r) * a.ldv + h * 64 + 2 * vdp);
+            }
+            const f32x8_t vt = {vv[0][0], vv[1][0], vv[2][0], vv[3][0], vv[0][1], vv[1][1], vv[2][1], vv[3][1]};   // d = 2 vdp: 4 keys, d + 1: 4 keys
+            if constexpr (F16) amax = fmaxf(amax, fmaxf(absmax8(kv), absmax8(vt)));
+            u32x4_t k_hi, k_lo, v_hi, v_lo;
+            split8<MODE>(kv, k_hi, k_lo);
+            split8<MODE>(vt, v_hi, v_lo);
+            Ks[0][skey * 8 + (sc ^ (skey & 7))] = k_hi;
+            if constexpr (F16) Ks[1][skey * 8 + (sc ^ (skey & 7))] = k_lo;
+            // rows d = 2 vdp and 2 vdp + 1 share (d >> 1) & 7 = vdp & 7
+            const int vch = vkg ^ (vdp & 7);
+            Vt[0][(2 * vdp) * 8 + vch] = u32x2_t{v_hi[0], v_hi[1]};
+            Vt[0][(2 * vdp + 1) * 8 + vch] = u32x2_t{v_hi[2], v_hi[3]};
+            if constexpr (F16) {
+                Vt[1][(2 * vdp) * 8 + vch] = u32x2_t{v_lo[0], v_lo[1]};
+                Vt[1][(2 * vdp + 1) * 8 + vch] = u32x2_t{v_lo[2], v_lo[3]};
+            }
+        }
+        if (tid < 32) {
+            const int kk = k0 + tid;
+            Bias[tid] = (kk >= tk) ? -INFINITY : ((pad && pad[(size_t)u * tk + kk]) ? -1e9f : 0.0f);
+        }
+        __syncthreads();
+
+        f32x16 s, s2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int ch = (2 * s4 + half) ^ (l31 & 7);
+            const u32x4_t kh = Ks[0][l31 * 8 + ch];
+            if constexpr (F16) {
+                const u32x4_t kl = Ks[1][l31 * 8 + ch];
+                s2 = mma32x16<MODE>(kh, ql[s4], s2);
+                s2 = mma32x16<MODE>(kl, qh[s4], s2);
+                s = mma32x16<MODE>(kh, qh[s4], s);
+            } else {
+                s = mma32x16<MODE>(kh, ql[s4], s);
+                s = mma32x16<MODE>(kh, qh[s4], s);
+            }
+        }
+        // s[r] = S[query l31][key k0 + (r&3) + 8*(r>>2) + 4*half]
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kl = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if constexpr (F16) s[r] += s2[r] * (1.0f / ATT_F16_SCALE);
+            s[r] = s[r] + Bias[kl];
+            if (a.causal && k0 + kl > q) s[r] += -1e9f;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); ls += s[r]; }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; o2[0][r] *= alpha; if constexpr (F16) o2[1][r] *= alpha; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f32x8_t p8 = {s[8 * ks], s[8 * ks + 1], s[8 * ks + 2], s[8 * ks + 3], s[8 * ks + 4], s[8 * ks + 5], s[8 * ks + 6], s[8 * ks + 7]};
+            u32x4_t ph, pl;
+            split8<MODE>(p8, ph, pl);
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh) {
+                const int d = l31 + 32 * dh, sw = (d >> 1) & 7;
+                const u32x2_t c0 = Vt[0][d * 8 + ((4 * ks + half) ^ sw)], c1 = Vt[0][d * 8 + ((4 * ks + 2 + half) ^ sw)];
+                const u32x4_t vh = {c0[0], c0[1], c1[0], c1[1]};
+                if constexpr (F16) {
+                    const u32x2_t e0 = Vt[1][d * 8 + ((4 * ks + half) ^ sw)], e1 = Vt[1][d * 8 + ((4 * ks + 2 + half) ^ sw)];
+                    const u32x4_t vl = {e0[0], e0[1], e1[0], e1[1]};
+                    o2[dh] = mma32x16<MODE>(vh, pl, o2[dh]);
+                    o2[dh] = mma32x16<MODE>(vl, ph, o2[dh]);
+                    o[dh] = mma32x16<MODE>(vh, ph, o[dh]);
+                } else {
+                    o[dh] = mma32x16<MODE>(vh, pl, o[dh]);
+                    o[dh] = mma32x16<MODE>(vh, ph, o[dh]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if constexpr (F16) {
+        // NaN and Inf fail the comparison too
+        if (!(amax < 65504.0f) && range_flag) atomicOr(range_flag, 1);
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v0 = o[0][r], v1 = o[1][r];
+        if constexpr (F16) { v0 += o2[0][r] * (1.0f / ATT_F16_SCALE); v1 += o2[1][r] * (1.0f / ATT_F16_SCALE); }
+        Os[wave][l31][d] = v0 / l_tot;
+        Os[wave][l31][d + 32] = v1 / l_tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = i * 64 + lane, row = idx >> 4, c = idx & 15;
+        if (q0w + row < t) {
+            f32x4 v;
+            v[0] = Os[wave][row][c * 4 + 0]; v[1] = Os[wave][row][c * 4 + 1];
+            v[2] = Os[wave][row][c * 4 + 2]; v[3] = Os[wave][row][c * 4 + 3];
+            *reinterpret_cast<f32x4*>(ctx + ((size_t)u * t + q0w + row) * hidden + h * 64 + c * 4) = v;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_mha(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* pad, int causal,
-                      int n, int tq, int tk, int heads, float* ctx, hipStream_t s)
+                      int n, int tq, int tk, int heads, float* ctx, int mode, int32_t* range_flag, hipStream_t s)
 {
     if (n <= 0 || tq <= 0) return hipSuccess;
     if (tk <= 0 || !q || !k || !v || !ctx || ((ldq | ldk | ldv) & 3) || (causal && tq != tk)) return hipErrorInvalidValue;
     MhaArgs a{q, k, v, ldq, ldk, ldv, pad, tq, tk, heads, causal, ctx};
-    hipLaunchKernelGGL(encoder_attention_kernel, dim3((tq + 127) / 128, heads, n), dim3(256), 0, s, a);
+    const dim3 grid((tq + 127) / 128, heads, n);
+    if (mode == 13) hipLaunchKernelGGL(encoder_attention16_kernel<13>, grid, dim3(256), 0, s, a, range_flag);
+    else if (mode == 1) hipLaunchKernelGGL(encoder_attention16_kernel<1>, grid, dim3(256), 0, s, a, nullptr);
+    else hipLaunchKernelGGL(encoder_attention_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads, float* ctx, hipStream_t s)
+hipError_t launch_encoder_attention(const float* qkv, const int32_t* pad, int n, int t, int heads, float* ctx, int mode,
+                                    int32_t* range_flag, hipStream_t s)
 {
     const int hidden = heads * 64;
-    return launch_mha(qkv, 3 * hidden, qkv + hidden, 3 * hidden, qkv + 2 * hidden, 3 * hidden, pad, 0, n, t, t, heads, ctx, s);
+    return launch_mha(qkv, 3 * hidden, qkv + hidden, 3 * hidden, qkv + 2 * hidden, 3 * hidden, pad, 0, n, t, t, heads, ctx, mode,
+                      range_flag, s);
 }
 
 size_t self_attention_lds_bytes(int k, int lds_stride)

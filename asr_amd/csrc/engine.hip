@@ -325,6 +325,15 @@ inline int split_tile_for(const asr_handle* h, int M, int N, int K, int split_k,
 // Measurement aid (ASR_AMD_DOUBLE=glu|proj|qkv|ffn2|logits|self|cross|ln|topk|encoder): the decode-step kernels of that class are launched
 // twice - every one of them is idempotent (same inputs, same outputs) - so the change in step time is what that class costs
 // with everything else as it is (the costs add up to the step).  1 launch when unset.
+// Arithmetic of the many-query attention kernels (attention.hip launch_mha) for this handle's current mode: the dense layers'
+// fp16x3 / bf16 product schemes, or the exact-f32 matrix instruction (f32, f32_bf16x6, bf16x3, and an fp16x3 call that is being
+// repeated after a range flag).  ASR_AMD_MHA_EXACT=1: development (always exact).
+inline int mha_mode(const asr_handle* h)
+{
+    static const bool exact = getenv("ASR_AMD_MHA_EXACT") && atoi(getenv("ASR_AMD_MHA_EXACT")) != 0;
+    if (exact) return 0;
+    return h->nprod_active == 13 ? 13 : (h->nprod_active == 1 ? 1 : 0);
+}
 inline int launches_of(const asr_handle* h, const char* cls) { return (!h->twice.empty() && h->twice == cls) ? 2 : 1; }
 
 const char* gemm_class_name(const asr_handle* h, int nprod, int M, int N, int K, int epilogue, int split_k)
@@ -697,11 +706,11 @@ int run_encoder(asr_handle* h, const float* X_dev, int n, int t, const Groups* g
             if (gr) {
                 size_t row0 = 0;
                 for (int g = 0; g < gr->count; ++g) {
-                    HIP_TRY(h, launch_encoder_attention(h->qkv + row0 * 3 * H, h->pad + row0, gr->n[g], gr->t[g], h->heads, h->x1 + row0 * H, s));
+                    HIP_TRY(h, launch_encoder_attention(h->qkv + row0 * 3 * H, h->pad + row0, gr->n[g], gr->t[g], h->heads, h->x1 + row0 * H, mha_mode(h), h->range_flag, s));
                     row0 += (size_t)gr->n[g] * gr->t[g];
                 }
             } else {
-                HIP_TRY(h, launch_encoder_attention(h->qkv, h->pad, n, t, h->heads, h->x1, s));     // utils.py:624-631
+                HIP_TRY(h, launch_encoder_attention(h->qkv, h->pad, n, t, h->heads, h->x1, mha_mode(h), h->range_flag, s));     // utils.py:624-631
             }
         }
         rc = gemm(h, h->x1, b.wo, nullptr, h->x2, M, H, H, EPI_PARTIAL, 1);                         // utils.py:632
@@ -1659,12 +1668,12 @@ static int asr_loss_once(asr_handle* h, const float* X, int32_t n, int32_t t, in
     for (int l = 0; l < h->L; ++l) {
         const DecBlock& b = h->dec[l];
         if ((rc = gemm(h, y0, b.wqkv, b.bqkv, qkv, Md, 3 * H, H, EPI_BIAS, 1))) return rc;
-        HIP_TRY(h, launch_mha(qkv, 3 * H, qkv + H, 3 * H, qkv + 2 * H, 3 * H, nullptr, 1, n, ty, ty, h->heads, ctx, s));   // :516-529
+        HIP_TRY(h, launch_mha(qkv, 3 * H, qkv + H, 3 * H, qkv + 2 * H, 3 * H, nullptr, 1, n, ty, ty, h->heads, ctx, mha_mode(h), h->range_flag, s));   // :516-529
         if ((rc = gemm(h, ctx, b.wo, nullptr, part, Md, H, H, EPI_PARTIAL, 1))) return rc;
         HIP_TRY(h, launch_add_layer_norm(y0, part, 1, 0, b.bo, b.ln0s, b.ln0b, nullptr, nullptr, Md, H, z1, s));
         if ((rc = gemm(h, z1, b.wq, b.bq, part, Md, H, H, EPI_BIAS, 1))) return rc;
         if ((rc = gemm(h, h->x0, b.wkv, b.bkv, kv, M, 2 * H, H, EPI_BIAS, 1))) return rc;
-        HIP_TRY(h, launch_mha(part, H, kv, 2 * H, kv + H, 2 * H, h->pad2, 0, n, ty, t, h->heads, ctx, s));              // :532-544
+        HIP_TRY(h, launch_mha(part, H, kv, 2 * H, kv + H, 2 * H, h->pad2, 0, n, ty, t, h->heads, ctx, mha_mode(h), h->range_flag, s));              // :532-544
         if ((rc = gemm(h, ctx, b.wco, nullptr, part, Md, H, H, EPI_PARTIAL, 1))) return rc;
         HIP_TRY(h, launch_add_layer_norm(z1, part, 1, 0, b.bco, b.ln1s, b.ln1b, nullptr, nullptr, Md, H, z2, s));
         if ((rc = gemm(h, z2, b.w1, b.b1, hid, Md, h->glu ? 2 * F : F, H, h->glu ? EPI_GLU : h->ff_epi, 1))) return rc;
@@ -2123,9 +2132,8 @@ int asr_op_input_norm_timing_noalloc(asr_handle* h, const float* x_dev, const fl
     return ASR_OK;
 }
 
-int asr_op_encoder_attention(asr_handle* h, const float* qkv, const int32_t* pad, int32_t n, int32_t t, float* ctx)
+static int asr_op_encoder_attention_once(asr_handle* h, const float* qkv, const int32_t* pad, int32_t n, int32_t t, float* ctx)
 {
-    if (!h || !qkv || !pad || !ctx || n < 1 || t < 1) return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
     int rc = set_device(h);
     if (rc) return rc;
     TmpBufs tb;
@@ -2136,10 +2144,17 @@ int asr_op_encoder_attention(asr_handle* h, const float* qkv, const int32_t* pad
     HIP_TRY(h, tb.up(&dq, qkv, rows * 3 * h->H, s));
     HIP_TRY(h, tb.up(&dp, pad, rows, s));
     HIP_TRY(h, tb.up<float>(&dc, nullptr, rows * h->H, s));
-    HIP_TRY(h, launch_encoder_attention(dq, dp, n, t, h->heads, dc, s));
+    HIP_TRY(h, launch_encoder_attention(dq, dp, n, t, h->heads, dc, mha_mode(h), h->range_flag, s));
     HIP_TRY(h, hipMemcpyAsync(ctx, dc, rows * h->H * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return ASR_OK;
+}
+
+int asr_op_encoder_attention(asr_handle* h, const float* qkv, const int32_t* pad, int32_t n, int32_t t, float* ctx)
+{
+    if (!h || !qkv || !pad || !ctx || n < 1 || t < 1) return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
+    // (fp16x3 mode: q, k or v outside fp16's range -> repeated on the exact-f32 matrix instruction, like a whole decode)
+    return with_range_retry(h, [&]() { return asr_op_encoder_attention_once(h, qkv, pad, n, t, ctx); });
 }
 
 int asr_op_log_softmax_topk(asr_handle* h, const float* logits, int32_t rows, int32_t vocab, int32_t k, float* values, int32_t* indices)

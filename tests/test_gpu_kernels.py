@@ -204,6 +204,42 @@ def test_encoder_attention(L, eng, n, t, lens):
     assert rel_err(ctx, want) < 5e-6
 
 
+def test_encoder_attention_per_precision_mode_and_range_guard(L):
+    """The many-query attention runs on the arithmetic of the handle's mode (attention.hip launch_mha): `f32_f16x3` = three
+    fp16 matrix products per multiply (bar: the exact-f32 kernel's own, 5e-6 of the float64 evaluation; observed 5e-7 against
+    6e-7 .. 1.1e-6 for the exact-f32 instruction), `f32` / `f32_bf16x6` = the exact-f32 instruction, `bf16` = K and V rounded
+    to bf16 (2e-2).  In `f32_f16x3` an operand outside fp16's range (|x| >= 65504) sets the range flag and the call is
+    repeated on the exact-f32 instruction: same bar, one retry counted."""
+    from asr_amd.model import Engine
+    from tests.helpers import product_config
+    ocfg = O.make_config(beam_size=2, max_target_length=4)
+    rng = np.random.default_rng(77)
+    n, t, lens = 3, 150, (150, 97, 5)
+    for prec, bar in (('f32_f16x3', 5e-6), ('f32', 5e-6), ('f32_bf16x6', 5e-6), ('bf16', 2e-2)):
+        e = Engine(product_config(ocfg, precision=prec), 0)
+        e.load_weights(O.random_weights(ocfg, seed=1))
+        try:
+            hidden, heads = e.hidden, e.cfg.num_heads
+            for scale_k in ((1.0, 3.0e5) if prec == 'f32_f16x3' else (1.0,)):
+                qkv = rng.standard_normal((n, t, 3 * hidden)).astype(np.float32)
+                qkv[:, :, :hidden] *= np.float32(1.0 / scale_k)                 # (keeps the logits in a sane range)
+                qkv[:, :, hidden:2 * hidden] *= np.float32(scale_k)             # k up to ~1.2e6: outside fp16
+                pad = np.zeros((n, t), np.int32)
+                for i, l in enumerate(lens):
+                    pad[i, l:] = 1
+                ctx = np.empty((n, t, hidden), np.float32)
+                before = e.range_retries()
+                L.check(e._h, L.lib.asr_op_encoder_attention(e._h, L.fptr(qkv), L.iptr(pad), n, t, L.fptr(ctx)))
+                assert e.range_retries() - before == (1 if scale_k > 1.0 else 0), (prec, scale_k)
+                q, k, v = np.split(qkv.astype(np.float64), 3, axis=2)
+                q = O.split_heads(q, heads) * 64 ** -0.5
+                bias = (pad.astype(np.float64) * -1e9)[:, None, None, :]
+                want = O.combine_heads(O.dot_product_attention(q, O.split_heads(k, heads), O.split_heads(v, heads), bias))
+                assert rel_err(ctx, want) < bar, (prec, scale_k, rel_err(ctx, want))
+        finally:
+            e.close()
+
+
 def test_encoder_attention_mask_gives_exact_zero_weight(L, eng):
     """Padded keys must not leak: changing their K/V rows leaves the context bit-identical."""
     hidden = eng.hidden
