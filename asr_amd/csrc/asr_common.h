@@ -148,6 +148,8 @@ struct SelfAttnArgs {
     float* ctx;            // [R, hidden]
     int b, k, heads, width;
     int lds_stride;        // >= (max position this decode can reach) + 1, <= width: row pitch of the LDS score / ancestry tables
+    int f16x3;             // float32 caches only: products as three fp16 MFMAs per multiply (operands must fit fp16's range)
+    int32_t* range_flag;   // f16x3: set when q, k or v of the new position does not fit (may be null)
 };
 size_t self_attention_lds_bytes(int k, int lds_stride);
 hipError_t launch_decoder_self_attention(const SelfAttnArgs& a, hipStream_t s);

@@ -298,9 +298,13 @@ __device__ __forceinline__ void kv_frags_bf16(const KvRegs<true>& r, bf16x4_t (&
 // key is not on that beam's ancestry are masked to -inf.  HBM traffic = live rows, not beams x pos.
 // The new position's K keys (one per beam, valid for that beam only) are taken from LDS.
 // ------------------------------------------------------------------------------------------------
-template <int NB, bool KV16>
-__global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArgs a)
+// F16X3 (`f32_f16x3`, float32 caches): the dot products as three fp16 matrix products per multiply, exactly as the cross-attention
+// kernel below does them; q, k and v of the new position are checked against fp16's range where they are assembled (every
+// history row was checked the same way by the step that wrote it), range flag -> the engine repeats the call with F16X3 off.
+template <int NB, bool KV16, bool F16X3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 3 : (F16X3 ? 1 : 2)))) void decoder_self_attention_kernel(SelfAttnArgs a)
 {
+    static_assert(!(KV16 && F16X3), "bf16 caches go to the bf16 matrix instruction");
     if (*a.done) return;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int BEAMS = NB * 16;
@@ -337,6 +341,9 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
             k4 += *reinterpret_cast<const f32x4*>(bp + hidden);
             v4 += *reinterpret_cast<const f32x4*>(bp + 2 * hidden);
             q4 = q4 * 0.125f;
+            if constexpr (F16X3) {
+                if (!(fits_f16(q4) && fits_f16(k4) && fits_f16(v4)) && a.range_flag) atomicOr(a.range_flag, 1);
+            }
             const size_t off = ((((size_t)u * a.heads + h) * width + pos) * K + kb) * 64 + cc * 4;   // head-major cache
             if constexpr (KV16) {
                 // the row is used as the cache will return it from the next step on: rounded once, here
@@ -377,6 +384,13 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
 #pragma unroll
             for (int db = 0; db < 4; ++db) split_bf16x2(qf[nb][db], qbh[nb][db], qbl[nb][db]);
     }
+    f16x4_t qh[F16X3 ? NB : 1][4], ql[F16X3 ? NB : 1][4];
+    if constexpr (F16X3) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) split_f16x2(qf[nb][db], qh[nb][db], ql[nb][db]);
+    }
     float m_run[NB], l_run[NB];
     f32x4 o[NB][4];
 #pragma unroll
@@ -391,10 +405,29 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
     // KV16: kop / vop are bf16 fragments (K in kv_d_of order; V tile j = V[key 4g + r][d = 4c + j], r = 0..3) for the bf16
     // matrix instruction, q and P go in as two bf16 terms; otherwise float32 rows for the exact-f32 instruction
     auto compute = [&](const auto (&kop)[4], const auto (&vop)[4], const int (&cj)[4], const int (&cs)[4]) {
+        f16x4_t kh[4], kl[4], vh[4], vl[4];
+        if constexpr (F16X3) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) split_f16x2(kop[db], kh[db], kl[db]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                       // tile j: V[key 4g + r][d = 4c + j], r = 0..3 (the MFMA's k = key)
+                const f32x4 tv = {vop[0][j], vop[1][j], vop[2][j], vop[3][j]};
+                split_f16x2(tv, vh[j], vl[j]);
+            }
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (KV16) {
+            if constexpr (F16X3) {
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    sc = mfma16(kh[db], ql[nb][db], sc);
+                    sc = mfma16(kl[db], qh[nb][db], sc);
+                    s = mfma16(kh[db], qh[nb][db], s);
+                }
+                s = s + sc * (1.0f / ATT_F16_SCALE);
+            } else if constexpr (KV16) {
 #pragma unroll
                 for (int db = 0; db < 4; ++db) {
                     s = mfma16(kop[db], qbl[nb][db], s);
@@ -427,7 +460,18 @@ __global__ __launch_bounds__(256) void decoder_self_attention_kernel(SelfAttnArg
             m_run[nb] = m_new;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[nb][j] = o[nb][j] * alpha;
-            if constexpr (KV16) {
+            if constexpr (F16X3) {
+                f16x4_t ph, pl;
+                split_f16x2(s, ph, pl);                         // P^T[key 4g + r][beam c]: the B operand, k = key
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 tc = {0.f, 0.f, 0.f, 0.f};
+                    tc = mfma16(vh[j], pl, tc);
+                    tc = mfma16(vl[j], ph, tc);
+                    o[nb][j] = mfma16(vh[j], ph, o[nb][j]);
+                    o[nb][j] = o[nb][j] + tc * (1.0f / ATT_F16_SCALE);
+                }
+            } else if constexpr (KV16) {
                 bf16x4_t pbh, pbl;
                 split_bf16x2(s, pbh, pbl);
 #pragma unroll
@@ -1041,10 +1085,10 @@ size_t self_attention_lds_bytes(int k, int lds_stride)
     return (size_t)3 * nb * 16 * 64 * sizeof(float) + (lists > merge ? lists : merge);
 }
 
-template <int NB, bool KV16>
+template <int NB, bool KV16, bool F16X3>
 hipError_t launch_self(const SelfAttnArgs& a, size_t lds, hipStream_t s)
 {
-    auto kern = decoder_self_attention_kernel<NB, KV16>;
+    auto kern = decoder_self_attention_kernel<NB, KV16, F16X3>;
     static std::atomic<bool> attr_done[64];      // zero-initialised; several handles' host threads may launch first at once (the call is idempotent)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -1064,8 +1108,9 @@ hipError_t launch_decoder_self_attention(const SelfAttnArgs& a, hipStream_t s)
     const size_t lds = self_attention_lds_bytes(a.k, a.lds_stride);
     if (lds > 150 * 1024 || a.k > ASR_MAX_BEAM || a.lds_stride > a.width || a.lds_stride < 2 || !a.live || !a.live_cnt)
         return hipErrorInvalidValue;
-    if (a.kv_bf16) return a.k <= 16 ? launch_self<1, true>(a, lds, s) : launch_self<2, true>(a, lds, s);
-    return a.k <= 16 ? launch_self<1, false>(a, lds, s) : launch_self<2, false>(a, lds, s);
+    if (a.kv_bf16) return a.k <= 16 ? launch_self<1, true, false>(a, lds, s) : launch_self<2, true, false>(a, lds, s);
+    if (a.f16x3) return a.k <= 16 ? launch_self<1, false, true>(a, lds, s) : launch_self<2, false, true>(a, lds, s);
+    return a.k <= 16 ? launch_self<1, false, false>(a, lds, s) : launch_self<2, false, false>(a, lds, s);
 }
 
 hipError_t launch_decoder_cross_attention(const CrossAttnArgs& a, hipStream_t s)

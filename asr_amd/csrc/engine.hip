@@ -334,6 +334,11 @@ inline int mha_mode(const asr_handle* h)
     if (exact) return 0;
     return h->nprod_active == 13 ? 13 : (h->nprod_active == 1 ? 1 : 0);
 }
+inline bool self_exact()                  // ASR_AMD_SELF_EXACT=1 (development): decode self-attention on the exact-f32 instruction in every mode
+{
+    static const bool v = getenv("ASR_AMD_SELF_EXACT") && atoi(getenv("ASR_AMD_SELF_EXACT")) != 0;
+    return v;
+}
 inline int launches_of(const asr_handle* h, const char* cls) { return (!h->twice.empty() && h->twice == cls) ? 2 : 1; }
 
 const char* gemm_class_name(const asr_handle* h, int nprod, int M, int N, int K, int epilogue, int split_k)
@@ -837,6 +842,8 @@ int step_attention_half(asr_handle* h, const DecView& v, const StepCtx& c, int l
         const size_t esz = h->kv_bf16 ? 2 : 4;                       // bytes per cached value
         a.kcache = reinterpret_cast<char*>(h->kcache[l]) + v.cache_off * esz; a.vcache = reinterpret_cast<char*>(h->vcache[l]) + v.cache_off * esz;
         a.kv_bf16 = h->kv_bf16 ? 1 : 0;
+        a.f16x3 = (h->nprod_active == 13 && !h->kv_bf16 && !self_exact()) ? 1 : 0;
+        a.range_flag = a.f16x3 ? h->range_flag : nullptr;
         a.anc0 = st.anc[0]; a.anc1 = st.anc[1]; a.live = st.live; a.live_cnt = st.live_cnt; a.pos = st.pos; a.done = st.done;
         a.ctx = v.dctx; a.b = n; a.k = K; a.heads = h->heads; a.width = st.width;
         a.lds_stride = std::min(st.width, st.limit + 2);
@@ -1999,6 +2006,9 @@ int asr_op_decoder_self_attention(asr_handle* h, const float* qkv, const float* 
         (pos > 0 && (!hist_k || !hist_v || !anc)))
         return h ? fail(h, ASR_ERR_ARG, "bad argument") : ASR_ERR_ARG;
     const int K = beams, width = std::max(pos + 1, 2);
+    if (kv_bf16 < 0 || kv_bf16 > 2) return fail(h, ASR_ERR_ARG, "variant must be 0 (float32), 1 (bf16 caches) or 2 (float32 caches, fp16x3 products)");
+    const bool f16x3 = kv_bf16 == 2;
+    if (f16x3) kv_bf16 = 0;
     const size_t hidden = (size_t)heads * ASR_D_HEAD, R = (size_t)n * K, esz = kv_bf16 ? 2 : 4;
     if (self_attention_lds_bytes(K, width) > 150 * 1024) return fail(h, ASR_ERR_CAPACITY, "beams x positions beyond the kernel's LDS tables");
     for (size_t i = 0; i < (size_t)n * K * pos; ++i)
@@ -2055,7 +2065,7 @@ int asr_op_decoder_self_attention(asr_handle* h, const float* qkv, const float* 
     HIP_TRY(h, tb.up<float>(&dctx, nullptr, R * hidden, s));
     SelfAttnArgs a{};
     a.qkv = dqkv; a.nsplit = 1; a.split_stride = 0; a.bias = dbias;
-    a.kcache = dk; a.vcache = dv; a.kv_bf16 = kv_bf16 ? 1 : 0;
+    a.kcache = dk; a.vcache = dv; a.kv_bf16 = kv_bf16 ? 1 : 0; a.f16x3 = f16x3 ? 1 : 0; a.range_flag = nullptr;
     a.anc0 = danc; a.anc1 = danc; a.live = dlive; a.live_cnt = dcnt; a.pos = dflags; a.done = dflags + 1;
     a.ctx = dctx; a.b = n; a.k = K; a.heads = heads; a.width = width; a.lds_stride = width;
     HIP_TRY(h, launch_decoder_self_attention(a, s));

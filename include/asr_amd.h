@@ -249,7 +249,9 @@ int asr_op_decoder_cross_attention(asr_handle* h, const float* q, const float* q
  * anc [n][beams][pos] = the slot of beam b's ancestor at position j (what the reference gets by gathering its cache with
  * the surviving beams' indices, model.py:296-301; here rows never move).  -> ctx [n*beams, heads*64].  Builds the cache,
  * the ancestry table and the list of live (position, slot) rows as the engine holds them and runs the decode step's own
- * kernel; kv_bf16 = the `precision: bf16` variant (cache rows and the new rows rounded to bf16). pos may be 0. */
+ * kernel; kv_bf16 = 1: the `precision: bf16` variant (cache rows and the new rows rounded to bf16), 2: float32 caches with the
+ * products as three fp16 matrix products per multiply (what `f32_f16x3` runs; operands must fit fp16's range), 0: float32 caches
+ * on the exact-f32 matrix instruction. pos may be 0. */
 int asr_op_decoder_self_attention(asr_handle* h, const float* qkv, const float* bias, const float* hist_k, const float* hist_v,
                                   const int32_t* anc, int32_t n, int32_t pos, int32_t heads, int32_t beams, int32_t kv_bf16,
                                   float* ctx);

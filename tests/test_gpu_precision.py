@@ -158,6 +158,33 @@ def test_f16x3_cross_attention_keys_outside_fp16_range_are_redone_with_exact_pro
         eng.close()
 
 
+def test_f16x3_self_attention_keys_outside_fp16_range_are_redone_with_exact_products():
+    """The default mode's decode-time self-attention multiplies on the fp16 matrix pipe too (round 3).  Keys of magnitude >=
+    65504 (the k rows of the decoder's qkv_transform scaled up; the weights themselves and every GEMM operand stay in range -
+    k only enters the attention scores) are caught where the new position's q, k, v are assembled: the call is repeated with
+    the exact-f32 products and gives the oracle's hypotheses."""
+    ocfg = tiny_config(beam_size=3, max_target_length=10)
+    W = dict(O.random_weights(ocfg, seed=6, bias_scale=0.1))
+    H = ocfg.hidden_units
+    for l in range(ocfg.num_blocks):
+        name = 'decoder/block_%d/decoder_self_attention/qkv_transform/kernel' % l
+        w = W[name].copy()
+        w[H:2 * H] *= np.float32(2.0e5)                            # k = rows H..2H-1 (utils.py:612-615)
+        assert np.abs(w).max() < 65504.0                           # the weights themselves still fit fp16
+        W[name] = w
+    X = tiny_inputs((60, 90, 75), seed=16)
+    eng = _engine(ocfg, 'f32_f16x3', W)
+    try:
+        want = O.build_test_model(X, W, ocfg, num_gpus=1, algo='kv')
+        want64 = O.build_test_model(X.astype(np.float64), O.cast_weights(W, np.float64), ocfg, num_gpus=1, algo='kv')
+        assert np.array_equal(want, want64), 'near-tie in the oracle: pick another seed'
+        Y = eng.decode(X)
+        assert eng.range_retries() == 1
+        assert Y.shape == want.shape and np.array_equal(Y, want)
+    finally:
+        eng.close()
+
+
 def test_dense_glu_modes(mode_eng):
     from asr_amd import _lib as L
     mode, eng = mode_eng
