@@ -319,6 +319,11 @@ inline int split_tile_for(const asr_handle* h, int M, int N, int K, int split_k,
     static const int forced = getenv("ASR_AMD_DECODE_TILE") ? atoi(getenv("ASR_AMD_DECODE_TILE")) : 0;   // development: 2, 6 or 9 for the decode rows
     if (forced && M <= 4096) return forced;
     const int t = gemm_split_pick_tile(M, N, K, split_k, epilogue);
+    // One-product mode (bf16) with handles sharing the GPU, two whole batches per call (1000+ beam rows): a k-tile's side work
+    // (loads, A staging, fragment reads) outweighs its four matrix instructions at 64 rows, so 128 x 256 tiles - the same side
+    // work for eight.  Same box, four handles x two steps: 104.7 -> 103.3 ms per step (config 5: 132.0 -> 131.0); the three-product
+    // mode loses 7 % with it (its k-tiles are matrix-bound and fewer workgroups balance worse).
+    if (h->nprod_active == 1 && h->shared_gpu && M >= 1000 && M <= 4096 && t == 9) return 10;
     return (t == 6 && h->shared_gpu) ? 9 : t;
 }
 

@@ -13,7 +13,7 @@ step() { echo "== $1" >&2; }
 
 step "kernel stats"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r03_ks -o ks -- python3 $B > $O/bench_line_under_rocprof.json 2> /tmp/r03_ks.err || { tail -5 /tmp/r03_ks.err; exit 1; }
-f=$(find /tmp/r03_ks -name 'ks_kernel_stats.csv' | head -1); cp "$f" $O/r03_bench_kernel_stats_v17.csv
+f=$(find /tmp/r03_ks -name 'ks_kernel_stats.csv' | head -1); cp "$f" $O/r03_bench_kernel_stats_v19.csv
 t=$(find /tmp/r03_ks -name 'ks_kernel_trace.csv' | head -1)
 python3 $R/tools/trace_overlap.py "$t" $O/r03_trace_overlap.json > /dev/null || exit 1
 
