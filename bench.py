@@ -811,7 +811,7 @@ def main():
                     continue
                 p2 = EnginePool(bench_config(args.beam, args.max_target_length, prec, args.vocab), local_rank, args.in_flight)
                 p2.load_weights(W)
-                run_steps(p2, len(p2.engines))                           # warm-up
+                run_steps(p2, spd * len(p2.engines))                     # warm-up: one call of the timed size on every handle
                 dt, Ya = timed(p2, args.alt_steps)
                 m = min(Ya.shape[1], Y.shape[1])
                 same = np.all(Ya[:, :m] == Y[:, :m], axis=1)
