@@ -591,7 +591,9 @@ int decode_splits(const asr_handle* h, int R, int* s_qkv, int* s_proj, int* s_ff
     // (ms per batch): 2,2,8 (the values above) 212.3; 1,1,1 219.4; 1,1,2 204.8; 1,1,4 205.3; 1,2,4 206.5; 2,2,4 208.4; 1,1,8 208.8.
     // Ten-utterance batches lose with fewer slices (1377 -> 1160 audio-s/s): only for whole-batch row counts.
     // One-product mode (bf16), same sweep: 1,1,2 125.9; 1,1,4 122.2; 1,2,4 123.7; 2,2,4 126.0; 2,2,8 128.9; 1,1,1 132.0.
-    if (h->shared_gpu && R >= whole_batch_rows()) { *s_qkv = 1; *s_proj = 1; *s_ffn2 = h->nprod_active == 1 ? 4 : 2; }
+    // Round 3, two whole batches per call (1280 rows), bf16: 1,1,2 103.5 ms per step; 1,1,4 105.3; 1,1,1 104.2 - two slices in every mode
+    // (three-product mode at 1280 rows: 1,1,2 187.5; 1,1,1 187.9; 1,1,4 189.9).
+    if (h->shared_gpu && R >= whole_batch_rows()) { *s_qkv = 1; *s_proj = 1; *s_ffn2 = 2; }
     if (const char* e = getenv("ASR_AMD_SPLITS")) {                  // development: "qkv,proj,ffn2"
         int a = 0, b = 0, c = 0;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 1 && b >= 1 && c >= 1 && a <= ASR_MAX_SPLITK && b <= ASR_MAX_SPLITK &&
