@@ -449,3 +449,13 @@ def test_predict_batches_pairs_whole_batches_and_keeps_their_order():
             assert sorted(calls) == sorted([[64, 64], [64], [5], [64, 60], [44], [64, 45], [50]])
         else:
             assert sorted(calls) == sorted([[64], [64], [64], [5], [64], [60], [44], [64], [45], [50]])
+
+
+def test_pairing_threshold_matches_the_engine():
+    """asr_amd.model pairs batches from the row count at which the engine's shared-GPU K-slice rule stops following the number of
+    rows (engine.hip WHOLE_BATCH_ROWS_DEFAULT): the two constants must stay one number, or a pair could differ from its halves."""
+    import re
+    from asr_amd import model
+    src = open(os.path.join(os.path.dirname(model.__file__), 'csrc', 'engine.hip')).read()
+    m = re.search(r'constexpr int WHOLE_BATCH_ROWS_DEFAULT = (\d+);', src)
+    assert m and int(m.group(1)) == model.PAIR_MIN_ROWS
