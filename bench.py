@@ -351,12 +351,19 @@ def run_bucketed(args, rank, local_rank, world, rehearse, W=None):
 
 def plan_calls(k, handles, per_call):
     """k steps as library calls of at most `per_call` steps for a pool of `handles`: every handle gets the same number of steps
-    (+- 1), in calls as large as allowed, the large calls first - so that the last round of a finite run does not leave
-    handles idle while one of them still decodes a pair (a stream of batches without end has no such tail)."""
+    (+- 1), in calls of `per_call` steps (a handle's odd last step makes its last call one larger), the large calls first - so
+    that the last round of a finite run does not leave handles idle while one of them still decodes a pair (a stream of batches
+    without end has no such tail)."""
     per_handle = [k // handles + (1 if i < k % handles else 0) for i in range(handles)]
     calls = []
     for steps in per_handle:
-        calls += [per_call] * (steps // per_call) + ([steps % per_call] if steps % per_call else [])
+        q, r = divmod(steps, per_call)
+        mine = [per_call] * q
+        if r == 1 and q and per_call >= 2:
+            mine[-1] += 1                        # a handle's odd last step joins its last call (one more batch in the same joint decode:
+        elif r:                                  # same hypotheses, and no round of single-step calls at the end of the run)
+            mine.append(r)
+        calls += mine
     return sorted(calls, reverse=True)
 
 
@@ -624,7 +631,10 @@ def main():
     spd = args.steps_per_decode
     raw = synthetic_raw(n, t_raw, seed=1000 + rank)
     # the second batch of a pair is another batch (other utterances): nothing is shared between the two but the kernels
-    raw_pair = np.concatenate([raw] + [synthetic_raw(n, t_raw, seed=2000 * i + rank) for i in range(1, spd)]) if spd > 1 else raw
+    # the largest call of the timed region (plan_calls: a handle's odd last step joins its last call) decides how many batches the
+    # device buffer holds and what the warm-up calls look like
+    largest = spd + 1 if spd >= 2 else 1
+    raw_pair = np.concatenate([raw] + [synthetic_raw(n, t_raw, seed=2000 * i + rank) for i in range(1, largest)]) if largest > 1 else raw
     d_raw = torch.from_numpy(raw_pair).cuda(local_rank)
     torch.cuda.synchronize()
     width = args.max_target_length + 1
@@ -634,7 +644,9 @@ def main():
     def decode(e, _=None):                                   # one step: the first batch alone
         return e.decode_dev(d_raw.data_ptr(), n, 0, 0, raw=front)
 
-    def decode_call(e, nsteps):                              # nsteps (1 or 2) steps in one library call -> their hypotheses, step by step
+    def decode_call(e, nsteps):                              # nsteps (1 .. largest) steps in one library call -> their hypotheses, step by step
+        if nsteps > largest:
+            raise ValueError('a call of %d steps, the device buffer holds %d batches' % (nsteps, largest))
         Y = e.decode_dev(d_raw.data_ptr(), nsteps * n, 0, 0, raw=front)
         return [Y[i * n:(i + 1) * n] for i in range(nsteps)]
 
@@ -674,8 +686,24 @@ def main():
         fence()
         return time.perf_counter() - t0, Y
 
-    # W untimed steps - and at least one call on every handle, so that no handle's first call falls into the timed region
-    Y = run_steps(pool, max(args.warmup, spd * len(pool.engines)) if args.warmup > 0 else 0)
+    def warm(p, k_timed, per_call=None, at_least=0):
+        """Untimed: one call of the largest size the timed plan for `k_timed` steps holds on every handle (a handle's caches grow
+        with the largest call it has seen - that must not happen inside the timed region), then what is left of `at_least` steps."""
+        per_call = per_call or spd
+        big = max(plan_calls(k_timed, len(p.engines), per_call) + [1])
+        Yw = None
+        for Ys in p.map(decode_call, [big] * len(p.engines)):
+            for Yi in Ys:
+                gather(Yi)                        # (the collective is warmed as well)
+            Yw = Ys[0]
+        left = at_least - big * len(p.engines)
+        if left > 0:
+            Yw = run_steps(p, left, per_call)
+        return Yw
+
+    # W untimed steps - and at least one call of the timed region's largest size on every handle
+    if args.warmup > 0:
+        warm(pool, args.steps, spd, args.warmup)
     elapsed, Y = timed(pool, args.steps)
     per_rank = [elapsed]
     if world > 1:
@@ -702,7 +730,7 @@ def main():
                                       ('%d steps in flight per GPU: %d engine handles, each decoding %s as one run of %d-row kernels; '
                                        'ms_per_step = elapsed / steps'
                                        % (nfl * spd, nfl, 'whole steps one after the other' if spd == 1 else
-                                          '%d steps (%d 64-utterance batches) per call' % (spd, spd), spd * n * args.beam))
+                                          '%d steps (%d 64-utterance batches) per call (one more when a handle is left with an odd last step)' % (spd, spd), spd * n * args.beam))
                                       if nfl > 1 else 'one step at a time'),
                        'batch_per_gpu': n, 'beam': args.beam, 'parallelism': 'dp%d' % world, 'precision': args.precision,
                        'steps_in_flight': nfl * spd, 'engine_handles': nfl, 'steps_per_decode': spd, 'hw_queues': HWQ['value'], 'hw_queues_source': HWQ['source'],
@@ -781,7 +809,7 @@ def main():
             # the same steps one at a time (one handle, the library's default: two half batches on two streams)
             p1 = EnginePool(cfg, local_rank, 1)
             p1.load_weights(W)
-            run_steps(p1, 1, 1)
+            warm(p1, args.alt_steps, 1)
             dt, Y1 = timed(p1, args.alt_steps, 1)
             m = min(Y1.shape[1], Y.shape[1])
             same = np.all(Y1[:, :m] == Y[:, :m], axis=1)
@@ -794,7 +822,7 @@ def main():
             # batch a call of its own
             p2 = EnginePool(cfg, local_rank, nfl)
             p2.load_weights(W)
-            run_steps(p2, nfl, 1)
+            warm(p2, args.alt_steps, 1)
             dt, Y2 = timed(p2, args.alt_steps, 1)
             m = min(Y2.shape[1], Y.shape[1])
             same = np.all(Y2[:, :m] == Y[:, :m], axis=1)
@@ -811,7 +839,7 @@ def main():
                     continue
                 p2 = EnginePool(bench_config(args.beam, args.max_target_length, prec, args.vocab), local_rank, args.in_flight)
                 p2.load_weights(W)
-                run_steps(p2, spd * len(p2.engines))                     # warm-up: one call of the timed size on every handle
+                warm(p2, args.alt_steps)                                 # one call of the timed size on every handle
                 dt, Ya = timed(p2, args.alt_steps)
                 m = min(Ya.shape[1], Y.shape[1])
                 same = np.all(Ya[:, :m] == Y[:, :m], axis=1)

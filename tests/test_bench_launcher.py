@@ -80,10 +80,14 @@ def test_plan_calls_gives_every_handle_the_same_number_of_steps():
         for handles in (1, 2, 3, 4, 6):
             for per_call in (1, 2, 3, 4):
                 calls = bench.plan_calls(k, handles, per_call)
-                assert sum(calls) == k and all(1 <= c <= per_call for c in calls)
+                assert sum(calls) == k and all(1 <= c <= per_call + (1 if per_call >= 2 else 0) for c in calls)
                 assert calls == sorted(calls, reverse=True)                   # the large calls first
-                # no more calls than a handle-by-handle split needs: every handle's share in calls as large as allowed
+                # every handle's share in calls of per_call steps; an odd last step joins the handle's last call
                 share = [k // handles + (1 if i < k % handles else 0) for i in range(handles)]
-                assert len(calls) == sum(-(-s // per_call) for s in share)
-    assert bench.plan_calls(20, 4, 2) == [2] * 8 + [1] * 4
+                want = sum((s // per_call) + (1 if (s % per_call > 1 or (s % per_call == 1 and (s < per_call or per_call == 1))) else 0) for s in share)
+                assert len(calls) == want, (k, handles, per_call, calls)
+    assert bench.plan_calls(20, 4, 2) == [3] * 4 + [2] * 4
     assert bench.plan_calls(8, 4, 2) == [2] * 4
+    assert bench.plan_calls(5, 4, 2) == [2, 1, 1, 1]
+    assert bench.plan_calls(10, 4, 2) == [3, 3, 2, 2]
+    assert bench.plan_calls(6, 4, 1) == [1] * 6
