@@ -253,3 +253,27 @@ def test_the_shipped_test_section_four_towers_on_one_gpu():
         for Y1, Ym, Yw in zip(one, many, want):
             assert np.array_equal(Y1, Yw)
             assert np.array_equal(Ym, Yw)
+
+
+def test_calls_of_one_two_and_three_whole_batches_give_bit_identical_hypotheses():
+    """bench.py decodes two 64-utterance batches per library call and three when a handle is left with an odd last step
+    (plan_calls).  Utterances are independent and, from 448 beam rows up, a handle that shares the GPU picks its K-slices
+    whatever the number of rows: 64, 128 and 192 utterances of one padded length in one call must give every utterance the
+    hypothesis its own 64-utterance batch gives, bit for bit - and the float32 oracle's."""
+    from asr_amd.model import Engine
+    ocfg = O.make_config(beam_size=10, max_target_length=4)
+    W = O.random_weights(ocfg, seed=51)
+    X = O.make_batch(O.synthetic_fbank(192, [96 - 3 * (i % 7) for i in range(192)], seed=77))
+    cfg = product_config(ocfg, sub_batches=1)
+    cfg.test['shared_gpu'] = 1
+    eng = Engine(cfg, 0)
+    eng.load_weights(W)
+    try:
+        alone = [eng.decode(X[i:i + 64]) for i in (0, 64, 128)]
+        two = eng.decode(X[:128])
+        three = eng.decode(X)
+        assert np.array_equal(two, np.concatenate(alone[:2]))
+        assert np.array_equal(three, np.concatenate(alone))
+        assert np.array_equal(alone[0], O.build_test_model(X[:64], W, ocfg, num_gpus=1, algo='kv'))
+    finally:
+        eng.close()
